@@ -1,0 +1,141 @@
+"""CPU tests that PIN THE ORACLE: against fixtures produced by the reference's
+own code (tests/golden/make_golden.py), against the reference's known-answer
+test, and against independent implementations available in the image."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import align_ref as O
+import synth
+from golden.make_golden import build_case_inputs
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CASES = json.load(open(os.path.join(G, "align_cases.json"), encoding="utf-8"))
+COSTS = np.load(os.path.join(G, "align_cost.npz"))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_alignment_matches_reference_fixture(case):
+    tokens, att, heads, mfcc, tok = build_case_inputs(case)
+    words, internals = O.perform_word_alignment_ref(
+        tokens, att, tok, use_space=case.get("use_space", True), mfcc=mfcc,
+        refine_whisper_precision_nframes=case["refine"],
+        remove_punctuation_from_words=case.get("remove_punct", False),
+        alignment_heads=None if heads is None else np.array(heads),
+        detect_disfluencies=case.get("disfl", False), return_internals=True)
+    # the f64 cost built by the reference's own lines 1540-1568 (captured at the dtw call)
+    ref_cost = COSTS[case["name"]].astype(np.float64)
+    assert internals["cost"].shape == tuple(case["cost_shape"])
+    assert np.array_equal(internals["cost"], ref_cost)
+    assert internals["index1s"].tolist() == case["index1s"]
+    assert internals["index2s"].tolist() == case["index2s"]
+    got = [dict(text=w["text"], start=w["start"], end=w["end"], tokens=w["tokens"],
+                tokens_indices=[int(x) for x in w["tokens_indices"]]) for w in words]
+    assert got == case["words"]
+
+
+def test_split_tokens_kat():
+    kat = json.load(open(os.path.join(G, "split_tokens_kat.json"), encoding="utf-8"))
+    for k in kat:
+        tok = synth.StubTokenizer(multilingual=k["multilingual"])
+        got = O.split_tokens_on_spaces_ref(list(k["tokens"]), tok)
+        assert got == (k["words"], k["word_tokens"], k["word_tokens_indices"]), k["source"]
+
+
+def test_find_start_padding_fixture():
+    for p in json.load(open(os.path.join(G, "find_start_padding.json"))):
+        rng = np.random.RandomState(p["seed"])
+        m = rng.standard_normal((1, p["n_mels"], 3000)).astype(np.float32)
+        if p["kind"] in ("zeros", "zero_col_inside"):
+            m[..., p["col"]:] = 0.0
+            if p["kind"] == "zero_col_inside":
+                m[..., 1000] = 0.0
+        elif p["kind"] == "allzero":
+            m[:] = 0.0
+        elif p["kind"] == "const_nonzero":
+            m[..., p["col"]:] = 0.5
+        assert O.find_start_padding_ref(torch.from_numpy(m)) == p["expected"], p
+
+
+def test_dtw_optimal_cost_vs_exhaustive_recurrence():
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        T, F = rng.randint(1, 8), rng.randint(1, 12)
+        c = -rng.rand(T, F)
+        r = O.dtw_ref(c, keep_internals=True)
+        assert np.isclose(r.distance, O.dtw_bruteforce_cost(c), rtol=0, atol=1e-12)
+        # path is monotone, single-step, closed ends, cost adds up exactly in path order
+        assert (r.index1s[0], r.index2s[0]) == (0, 0) and (r.index1s[-1], r.index2s[-1]) == (T - 1, F - 1)
+        d1, d2 = np.diff(r.index1s), np.diff(r.index2s)
+        assert set(zip(d1.tolist(), d2.tolist())) <= {(1, 1), (0, 1), (1, 0)}
+        acc = 0.0
+        for i, j in zip(r.index1s, r.index2s):
+            acc = acc + c[i, j] if (i, j) != (0, 0) else c[0, 0]
+        assert acc == r.distance
+
+
+def test_dtw_tie_order():
+    """All-equal costs: every candidate ties -> pattern 1 (diagonal) must win
+    where it exists, then pattern 2 (same token, previous frame): dtw-python's
+    strict '<' first-wins argmin."""
+    r = O.dtw_ref(np.zeros((3, 5)), keep_internals=True)
+    sm = r.directionMatrix
+    assert (sm[1:, 1:] == 1).all() and (sm[0, 1:] == 2).all() and (sm[1:, 0] == 3).all()
+    assert r.index1s.tolist() == [0, 0, 0, 1, 2] and r.index2s.tolist() == [0, 1, 2, 3, 4]
+    assert O.jumps_from_path(r.index1s, r.index2s).tolist() == [0, 3, 4, 4]
+
+
+def test_dtw_vs_transformers_on_tie_free_inputs():
+    gw = pytest.importorskip("transformers.models.whisper.generation_whisper")
+    rng = np.random.RandomState(1)
+    for _ in range(20):
+        T, F = rng.randint(2, 30), rng.randint(30, 200)
+        c = -rng.rand(T, F)
+        c[0, 0] = c.min()
+        r = O.dtw_ref(c)
+        ti, tj = gw._dynamic_time_warping(c)
+        assert np.array_equal(np.asarray(ti), r.index1s) and np.array_equal(np.asarray(tj), r.index2s)
+
+
+def test_dtw_rejects_nan():
+    c = np.zeros((3, 4)); c[1, 2] = np.nan
+    with pytest.raises(ValueError):
+        O.dtw_ref(c)
+
+
+def test_median_filter_is_half_sample_symmetric():
+    rng = np.random.RandomState(2)
+    for F in (1, 2, 3, 4, 5, 9, 17, 200):
+        x = rng.standard_normal((2, 3, F)).astype(np.float32)
+        got = O.median_filter(x, (1, 1, 9))
+        idx = np.arange(-4, F + 4)
+        m = np.mod(idx, 2 * F)
+        m = np.where(m < F, m, 2 * F - 1 - m)
+        xp = x[..., m]
+        want = np.stack([np.median(xp[..., k:k + 9], axis=-1) for k in range(F)], axis=-1)
+        assert np.array_equal(got, want.astype(np.float32)), F
+
+
+def test_mel_filters_vs_transformers():
+    au = pytest.importorskip("transformers.audio_utils")
+    for n in (80, 128):
+        want = au.mel_filter_bank(201, n, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+        got = O.mel_filters_ref(n).numpy()
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-7)
+
+
+def test_logmel_shapes_and_padding_detect():
+    rng = np.random.RandomState(3)
+    pcm = (0.1 * rng.standard_normal(16000 * 7)).astype(np.float32)
+    mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(torch.from_numpy(pcm)), 3000)
+    assert mel.shape == (80, 3000)
+    assert O.find_start_padding_ref(mel[None]) == 700
+
+
+def test_confidence_rounding():
+    lp = torch.tensor([-0.1, -0.2, -1.5])
+    assert O.confidence_ref(lp) == round(float(np.exp(np.float32(-0.6))), 3)
+    assert O.confidence_ref([]) == 0.0
