@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- whisper-timestamped alignment hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input that
+is already resident in HBM:  log-mel STFT front end -> padding detector ->
+local-cost construction (head select + median + softmax + head mean + column
+norm) -> DTW + backtrack + jumps -> chosen-token log-softmax gather
+(confidence), then an async copy of the (KB-sized) jumps/log-probs to the host.
+
+Workload at N=1 (BASELINE.json configs[1]): whisper-base, a batch of 32
+synthetic 30 s chunks; every chunk is one full-window alignment unit
+(A=8 alignment heads, T=224 tokens, F=1500 frames: the reference's
+trust_whisper_timestamps=False shape, SURVEY.md 8(d) "K-full"), V=51865.
+For N>1 every rank owns its own 32 chunks (units are independent: weak
+scaling, no data-path collective); the per-step result records are gathered
+to rank 0 over RCCL, which is where the reference assembles words.
+
+Prints ONE JSON line (rank 0).  metric = audio-seconds aligned per second.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    # name: (n_chunks, units per chunk generator)
+    "kfull": dict(n_chunks=32, A=8, T=224, F=1500, V=51865, n_mels=80,
+                  desc="whisper-base, 32 x 30 s chunks, one (8 heads,224 tokens,1500 frames) unit per chunk, V=51865"),
+}
+
+
+def make_workload(dev, cfg, seed):
+    from whisper_timestamped import _lib
+    n, A, T, F, V = cfg["n_chunks"], cfg["A"], cfg["T"], cfg["F"], cfg["V"]
+    g = torch.Generator(device=dev).manual_seed(seed)
+    qk = torch.randn((n, A, T, 1500), generator=g, device=dev, dtype=torch.float32)
+    # monotone ridge (+6 on a token->frame staircase, 3 frames wide): SURVEY.md 8(d) set K
+    rs = np.random.RandomState(seed)
+    stairs = np.sort(rs.randint(0, F, size=(n, T)), axis=1)
+    st = torch.from_numpy(stairs).to(dev)
+    fr = torch.arange(1500, device=dev).view(1, 1, 1500)
+    ridge = ((fr - st.unsqueeze(-1)).abs() <= 1).to(torch.float32) * 6.0
+    qk += ridge.unsqueeze(1)
+    del ridge
+    logits = torch.randn((n * T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
+    tokens = torch.randint(0, V, (n * T,), generator=g, device=dev, dtype=torch.int32)
+    pcm = torch.randn((n, 480000), generator=g, device=dev, dtype=torch.float32) * 0.1
+    from whisper_timestamped.audio import mel_filters
+    fb = mel_filters(dev, cfg["n_mels"])
+    descs = _lib.make_descs(n)
+    for b, d in enumerate(descs):
+        d["qk_offset"], d["head_stride"], d["row_stride"] = b * A * T * 1500, T * 1500, 1500
+        d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, 0, -1
+    n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
+    w = dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=fb, descs=descs,
+             descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
+             cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
+             jumps=torch.empty(n_jumps, dtype=torch.int32, device=dev),
+             logprob=torch.empty(n * T, dtype=torch.float32, device=dev),
+             mel=torch.empty((n, cfg["n_mels"], 3000), dtype=torch.float32, device=dev),
+             gmax=torch.empty(n, dtype=torch.float32, device=dev),
+             pad=torch.empty(n, dtype=torch.int32, device=dev),
+             host_jumps=torch.empty(n_jumps, dtype=torch.int32).pin_memory(),
+             host_logprob=torch.empty(n * T, dtype=torch.float32).pin_memory(),
+             stairs=stairs)
+    return w
+
+
+STAGES = ["logmel", "padding", "cost", "dtw", "logprob"]
+
+
+def run_step(w, ev=None):
+    """One pass of the hot path.  ev: optional list of 6 torch.cuda.Events (stage boundaries)."""
+    from whisper_timestamped import _lib
+    L = _lib.load()
+    cfg = w["cfg"]
+    n, T, V = cfg["n_chunks"], cfg["T"], cfg["V"]
+    st = torch.cuda.current_stream().cuda_stream
+    if ev: ev[0].record()
+    _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, 0, w["fb"].data_ptr(), cfg["n_mels"], 3000,
+                                  w["mel"].data_ptr(), w["gmax"].data_ptr(), st), "wt_logmel_batch")
+    if ev: ev[1].record()
+    _lib._check(L.wt_find_start_padding_batch(w["mel"].data_ptr(), n, cfg["n_mels"], 3000, w["pad"].data_ptr(), st),
+                "wt_find_start_padding_batch")
+    if ev: ev[2].record()
+    _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+                                w["head_idx"].data_ptr(), cfg["A"], 9, 1.0, w["cost"].data_ptr(), st), "wt_cost_batch")
+    if ev: ev[3].record()
+    _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+                               w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
+    if ev: ev[4].record()
+    _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n * T, V, w["tokens"].data_ptr(), 0, 0,
+                                          w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
+    if ev: ev[5].record()
+    w["host_jumps"].copy_(w["jumps"], non_blocking=True)
+    w["host_logprob"].copy_(w["logprob"], non_blocking=True)
+
+
+def algorithmic_bytes(cfg):
+    """Per launch (= per step on one rank), SURVEY.md 8(d)."""
+    n, A, T, F, V, M = cfg["n_chunks"], cfg["A"], cfg["T"], cfg["F"], cfg["V"], cfg["n_mels"]
+    return {
+        "logmel": n * (480000 * 4 + M * 3000 * 4),
+        "padding": n * M * 3000 * 4,
+        "cost": n * (A * T * F * 4 + T * F * 4),          # read selected-head logits once, write cost once
+        "dtw": n * (T * F * 4 + 4 * (T + 1)),             # read cost once, write jumps
+        "logprob": n * T * (V * 4 + 8),                   # read each logit row once
+    }
+
+
+def cpu_baseline(cfg, w, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path) on a bounded sample
+    of the same workload, host cores of this box, rank 0 only."""
+    from oracle import align_ref as O
+    qk = w["qk"][:4].cpu()
+    logits = w["logits"][: 4 * cfg["T"]].cpu()
+    tokens = w["tokens"][: 4 * cfg["T"]].cpu().numpy()
+    pcm = w["pcm"][:4].cpu()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        b = done % 4
+        mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b], cfg["n_mels"]), 3000)
+        O.find_start_padding_ref(mel[None])
+        cost = O.cost_matrix_ref(qk[b][:, :, :cfg["F"]], 9, 1.0, None, 0)
+        r = O.dtw_ref(cost)
+        O.jumps_from_path(r.index1s, r.index2s)
+        O.token_logprob_gather_ref(logits[b * cfg["T"]:(b + 1) * cfg["T"]], tokens[b * cfg["T"]:(b + 1) * cfg["T"]])
+        done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 64:
+            break
+    return {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": f"{done} of the same 30 s K-full chunks through oracle/ (scipy median_filter + torch CPU softmax/"
+                      f"mean/norm/log_softmax/stft with {torch.get_num_threads()} intra-op threads, single-thread C "
+                      f"DTW + backtrack), {el:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = WORKLOADS[args.workload]
+    w = make_workload(dev, cfg, seed=1234 + rank)
+    n, T = cfg["n_chunks"], cfg["T"]
+
+    gather_buf = None
+    if world > 1:
+        from whisper_timestamped.sharding import ResultGatherer
+        gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev)
+
+    def full_step(ev=None):
+        run_step(w, ev)
+        if gather_buf is not None:
+            gather_buf.gather(w["jumps"], w["logprob"])
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        full_step(evs[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # sanity inside the bench: the ridge is recovered and log-probs are finite
+    torch.cuda.synchronize()
+    j = w["host_jumps"].numpy().reshape(n, T + 1)
+    assert (j[:, 0] == 0).all() and (j[:, -1] == cfg["F"] - 1).all() and (np.diff(j, axis=1) >= 0).all()
+    assert np.median(np.abs(j[:, :-1] - w["stairs"])) <= 3
+    assert np.isfinite(w["host_logprob"].numpy()).all()
+
+    if rank == 0:
+        stage_ms = {s: float(np.mean([evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)]))
+                    for i, s in enumerate(STAGES)}
+        ab = algorithmic_bytes(cfg)
+        dom = max(stage_ms, key=stage_ms.get)
+        achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
+        stages = {s: {"ms": round(stage_ms[s], 4), "alg_MB": round(ab[s] / 1e6, 2),
+                      "GBps": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1),
+                      "frac_hbm": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for s in STAGES}
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks",
+            "value": round(world * n * 30.0 * args.steps / elapsed, 1),
+            "unit": "audio-seconds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (cost, log-softmax, mel) / f64 (DTW)",
+            "data": "synthetic",
+            "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
+                       "result_gather": "rccl gather to rank 0" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+            "stages": stages,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, w)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

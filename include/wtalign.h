@@ -1,0 +1,133 @@
+/*
+ * wtalign.h -- C ABI of libwtalign.so: the MI355X (gfx950) word-alignment hot
+ * path of whisper-timestamped.
+ *
+ * The reference (linto-ai/whisper-timestamped v1.15.9) is one pure-Python
+ * module; it has no FFI for this path.  Each entry point below replaces the
+ * numerics the reference reaches through Python at the cited lines of
+ * /root/reference/whisper_timestamped/transcribe.py ("T.py:N" below), and is
+ * what a ctypes binding inside the reference would call (INTEGRATION.md shows
+ * that binding).
+ *
+ * Conventions
+ *  - Every data pointer is a DEVICE pointer owned by the caller (PyTorch
+ *    allocations via tensor.data_ptr()), except arguments named *_host.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    calls are asynchronous with respect to that stream; nothing synchronises.
+ *  - Return value: 0 on success; <0 on error (WT_E_*), with a message
+ *    retrievable through wt_last_error() (thread-local).  Nothing throws.
+ *  - The library keeps one small lazily-allocated device scratch arena per
+ *    device (per-segment reduction words); wt_shutdown() frees it.
+ */
+#ifndef WTALIGN_H
+#define WTALIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WT_ABI_VERSION 1
+
+#define WT_OK 0
+#define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
+#define WT_E_HIP (-2)         /* a HIP runtime call failed (see wt_last_error)       */
+#define WT_E_UNSUPPORTED (-3) /* shape outside the kernels' range (T>256, F>1792,
+                                 T>F: the caller applies T.py:1516-1535 first)       */
+
+#define WT_DTYPE_F32 0
+#define WT_DTYPE_F16 1
+
+#define WT_N_AUDIO_CTX 1500 /* frames of 20 ms per 30 s window (T.py:44-47)       */
+#define WT_MAX_TOKENS 256   /* rows of one DTW (decoder emits <= 224 + 2)         */
+#define WT_MAX_FRAMES 1792
+
+/* One alignment unit = one call of perform_word_alignment (T.py:1428): a
+ * (heads, T tokens, F frames) window of cross-attention QK logits.
+ * Element offsets (not bytes).  The QK logits of flat head k (= layer*H+head),
+ * token row t, absolute frame f live at
+ *     qk[qk_offset + k*head_stride + t*row_stride + f]
+ * which covers both torch.cat(attention_weights) of T.py:1512 (head_stride =
+ * T*1500, row_stride = 1500) and a device-side capture ring. */
+typedef struct wt_seg_desc {
+    int64_t qk_offset;
+    int64_t head_stride;
+    int64_t row_stride;
+    int64_t cost_offset;  /* this unit's (T,F) row-major fp32 local-cost matrix in cost[]     */
+    int64_t jumps_offset; /* this unit's T+1 int32 entries in jumps[]                        */
+    int64_t path_offset;  /* this unit's (T+F-1)-capacity slot in path_i[] / path_j[]        */
+    int32_t T;            /* tokens incl. the start/end timestamp tokens (T.py:1514)         */
+    int32_t F;            /* end_token - start_token after T.py:1484-1489                    */
+    int32_t start_token;  /* first absolute frame of the window (T.py:1540)                  */
+    int32_t pad_from;     /* max_duration of T.py:1554-1565 when the mask applies, else -1.
+                             NB (reference quirk, reproduced): an ABSOLUTE frame index used
+                             as a column index RELATIVE to start_token.                      */
+} wt_seg_desc;
+
+int wt_version(void);
+const char *wt_last_error(void);
+int wt_shutdown(void);
+
+/* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
+ * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,
+ * softmax over the F-frame window, mean over heads, divide by the per-frame L2
+ * norm over tokens, negate, zero rows[:-1] of columns >= pad_from, then
+ * cost[0,0] = min(cost).  fp32 arithmetic like the reference's torch CPU ops;
+ * the result, widened to double, is the matrix the reference hands to dtw.dtw.
+ *   qk        : QK logits (fp32 or fp16 per qk_dtype), layout per wt_seg_desc
+ *   segs_host : n_seg descriptors in host memory (launch geometry)
+ *   segs_dev  : the same n_seg descriptors in device memory
+ *   head_idx  : device int32[n_heads], flat head indices in the order of
+ *               alignment_heads.indices().T (T.py:1545); all heads => 0..L*H-1
+ *   cost      : device fp32, written at segs[i].cost_offset (T*F each)       */
+int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                  const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, void *stream);
+
+/* T.py:1572,1581 dtw.dtw(cost, step_pattern=symmetric1) + T.py:1648-1652.
+ * dtw-python semantics (f64 accumulation; candidates diagonal, same-token/
+ * previous-frame, previous-token/same-frame; strict '<', first wins; closed
+ * ends), in-kernel backtrack.  Bit-exact integer outputs for a given cost.
+ *   jumps    : device int32, T+1 per unit at jumps_offset
+ *   path_i/j : optional (may be NULL) device int32, warping path
+ *              (alignment.index1s / index2s) at path_offset, forward order
+ *   path_len : optional device int32[n_seg]
+ *   dist     : optional device double[n_seg] = alignment.distance            */
+int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
+                 int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
+
+/* wt_cost_batch followed by wt_dtw_batch on the same stream. */
+int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                   const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
+                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
+
+/* T.py:1795-1805 find_start_padding on a batch of (n_mels, n_cols) log-mel
+ * windows: out[b] = None(-1) if the last column is not all-zero, else the
+ * index after the last column in [1, n_cols-2] that differs from zero, else 0. */
+int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, void *stream);
+
+/* Confidence path: T.py:871-876 (efficient: log_softmax of the filtered
+ * logits, gather of the chosen token T.py:735) and T.py:1245,1292 (naive).
+ * For each of n_rows rows of V fp32 logits (row r at logits + r*row_stride):
+ *     out[r] = log_softmax(row with suppressed entries at -inf)[token[r]]
+ *   suppress      : optional device uint8[n_rows_or_1][V] (1 = -inf), or NULL
+ *   suppress_rows : 0 = none, 1 = one shared mask row, n_rows = per-row masks */
+int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
+                            const int32_t *token, const uint8_t *suppress, int suppress_rows, float *out, void *stream);
+
+/* openai-whisper audio.log_mel_spectrogram + pad_or_trim as called at
+ * T.py:1213-1214 (naive path; n_frames = 3000) for a batch of equal-length
+ * PCM chunks: hann-400 STFT (centre, reflect pad), hop 160, |.|^2, mel
+ * (mel_fb: device fp32 [n_mels][201]), log10(max(.,1e-10)), max(x, max-8),
+ * (x+4)/4; columns >= n_valid_frames[b] are exact zeros (pad_or_trim).
+ *   pcm            : device fp32 [n_chunks][n_samples]
+ *   n_valid_samples: device int32[n_chunks] real samples per chunk (<= n_samples)
+ *   mel_out        : device fp32 [n_chunks][n_mels][n_frames]
+ *   gmax           : device fp32[n_chunks] scratch/out = per-chunk max of log10 mel */
+int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
+                    int n_mels, int n_frames, float *mel_out, float *gmax, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WTALIGN_H */

@@ -1,0 +1,392 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI,
+against the CPU oracle and the reference-generated fixtures.
+
+Bars (BASELINE.json north_star): integer outputs (DTW path, jumps) bit-exact
+for a given cost matrix; fp32 cost within 2e-6 relative of the oracle's torch
+CPU arithmetic (1-ulp-class reduction-order noise); word start/end within
++-0.02 s (one 20 ms frame); confidences within 1e-4 before rounding.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import align_ref as O
+import synth
+from golden.make_golden import build_case_inputs
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _lib():
+    from whisper_timestamped import _lib as L
+    return L
+
+
+def run_dtw(costs, want_path=True):
+    """costs: list of (T,F) float32 numpy -> per-unit (jumps, path_i, path_j, dist)."""
+    L = _lib()
+    descs = L.make_descs(len(costs))
+    for d, c in zip(descs, costs):
+        d["T"], d["F"] = c.shape
+        d["pad_from"] = -1
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    flat = np.zeros(n_cost, dtype=np.float32)
+    for d, c in zip(descs, costs):
+        flat[d["cost_offset"]:d["cost_offset"] + c.size] = c.ravel()
+    cost = torch.from_numpy(flat).to(DEV)
+    dd = L.descs_to_device(descs, DEV)
+    jumps = torch.full((n_jumps,), -7, dtype=torch.int32, device=DEV)
+    pi = torch.full((n_path,), -7, dtype=torch.int32, device=DEV)
+    pj = torch.full((n_path,), -7, dtype=torch.int32, device=DEV)
+    pl = torch.zeros(len(costs), dtype=torch.int32, device=DEV)
+    dist = torch.zeros(len(costs), dtype=torch.float64, device=DEV)
+    L.dtw_batch(cost, descs, dd, jumps, pi, pj, pl, dist)
+    torch.cuda.synchronize()
+    jumps, pi, pj, pl, dist = jumps.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), dist.cpu().numpy()
+    out = []
+    for k, (d, c) in enumerate(zip(descs, costs)):
+        T, F = c.shape
+        n = int(pl[k])
+        out.append((jumps[d["jumps_offset"]:d["jumps_offset"] + T + 1], pi[d["path_offset"]:d["path_offset"] + n],
+                    pj[d["path_offset"]:d["path_offset"] + n], float(dist[k])))
+    return out
+
+
+def check_dtw_exact(costs):
+    got = run_dtw(costs)
+    for c, (jm, pi, pj, dist) in zip(costs, got):
+        r = O.dtw_ref(c.astype(np.float64), keep_internals=True)
+        assert np.array_equal(pi, r.index1s), f"path_i differs for shape {c.shape}"
+        assert np.array_equal(pj, r.index2s), f"path_j differs for shape {c.shape}"
+        assert np.array_equal(jm, O.jumps_from_path(r.index1s, r.index2s)), f"jumps differ for shape {c.shape}"
+        assert dist == r.distance, (dist, r.distance)
+
+
+def test_dtw_bit_exact_random_shapes():
+    rng = np.random.RandomState(0)
+    costs = []
+    for _ in range(150):
+        T = int(rng.choice([1, 2, 3, 7, 16, 33, 63, 64, 65, 100, 128, 129, 191, 200, 225, 256]))
+        F = int(rng.choice([1, 2, 5, 15, 16, 17, 48, 49, 100, 144, 352, 700, 1500]))
+        costs.append((-rng.rand(T, F)).astype(np.float32))
+    check_dtw_exact(costs)
+
+
+def test_dtw_bit_exact_ties_and_masks():
+    """Exact ties everywhere (zeros, constant blocks, quantised costs): the
+    direction choice must follow dtw-python's first-wins strict '<'."""
+    rng = np.random.RandomState(1)
+    costs = [np.zeros((5, 9), np.float32), np.zeros((70, 300), np.float32), -np.ones((130, 200), np.float32)]
+    for _ in range(40):
+        T, F = int(rng.randint(2, 230)), int(rng.randint(2, 600))
+        c = -(rng.randint(0, 4, size=(T, F)) / 4.0).astype(np.float32)
+        if rng.rand() < 0.5:
+            c[:-1, int(F * rng.rand()):] = 0.0        # the reference's padding mask shape
+        c[0, 0] = c.min()
+        costs.append(c)
+    check_dtw_exact(costs)
+
+
+def test_dtw_bit_exact_max_sizes():
+    rng = np.random.RandomState(2)
+    costs = [(-rng.rand(256, 1792)).astype(np.float32), (-rng.rand(224, 1500)).astype(np.float32),
+             (-rng.rand(256, 256)).astype(np.float32), (-rng.rand(64, 1792)).astype(np.float32)]
+    check_dtw_exact(costs)
+
+
+def test_dtw_rejects_unsupported():
+    L = _lib()
+    descs = L.make_descs(1)
+    descs[0]["T"], descs[0]["F"] = 300, 100
+    L.layout_outputs(descs)
+    t = torch.zeros(300 * 100, device=DEV)
+    with pytest.raises(L.WtError):
+        L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(301, dtype=torch.int32, device=DEV))
+
+
+# ---------------------------------------------------------------------------
+def run_cost(qk_list, heads_list, windows, pads, dtype=torch.float32):
+    """qk_list[k]: (L*H, T, 1500) numpy; heads_list: flat head indices (shared); windows[k]=(start,end)."""
+    L = _lib()
+    n = len(qk_list)
+    descs = L.make_descs(n)
+    off = 0
+    for d, q, (s, e), p in zip(descs, qk_list, windows, pads):
+        d["qk_offset"] = off
+        d["head_stride"] = q.shape[1] * q.shape[2]
+        d["row_stride"] = q.shape[2]
+        d["T"], d["F"], d["start_token"], d["pad_from"] = q.shape[1], e - s, s, p
+        off += q.size
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    qk = torch.from_numpy(np.concatenate([q.ravel() for q in qk_list])).to(DEV).to(dtype)
+    hi = torch.tensor(heads_list, dtype=torch.int32, device=DEV)
+    cost = torch.full((n_cost,), float("nan"), dtype=torch.float32, device=DEV)
+    dd = L.descs_to_device(descs, DEV)
+    L.cost_batch(qk, descs, dd, hi, cost)
+    torch.cuda.synchronize()
+    c = cost.cpu().numpy()
+    return [c[d["cost_offset"]:d["cost_offset"] + d["T"] * d["F"]].reshape(d["T"], d["F"]) for d in descs]
+
+
+def oracle_cost(q, heads, window, pad):
+    s, e = window
+    sel = torch.from_numpy(q[heads][:, :, s:e])
+    md = pad if pad >= 0 else None
+    return O.cost_matrix_ref(sel, 9, 1.0, md, 0 if md else 0)
+
+
+def test_cost_matches_oracle():
+    rng = np.random.RandomState(3)
+    qk_list, windows, pads = [], [], []
+    heads = [25, 34, 35, 39, 41, 42, 44, 46]          # whisper-base alignment heads, flat l*8+h
+    shapes = [(2, 0, 3), (3, 10, 14), (5, 0, 9), (8, 100, 245), (18, 275, 523), (11, 0, 256), (11, 1, 258),
+              (40, 200, 968), (30, 0, 769), (60, 0, 1280), (33, 219, 1500), (64, 0, 1500), (10, 700, 1400)]
+    for k, (T, s, e) in enumerate(shapes):
+        qk_list.append(synth.synth_qk(100 + k, 48, T, lo=s, hi=e))
+        windows.append((s, e))
+        pads.append(-1 if k % 3 else max((e - s) // 2, 1))
+    got = run_cost(qk_list, heads, windows, pads)
+    worst = 0.0
+    for q, w, p, g in zip(qk_list, windows, pads, got):
+        ref = oracle_cost(q, heads, w, p)
+        assert g.shape == ref.shape and np.isfinite(g).all()
+        err = np.abs(g.astype(np.float64) - ref).max() / np.abs(ref).max()
+        worst = max(worst, err)
+        assert err < 2e-6, (w, err)
+        if p >= 0:
+            assert (g[:-1, p:] == 0).all() or (p == 0)
+        assert g[0, 0] == g.min()
+    print(f"max relative cost error vs oracle: {worst:.3e}")
+
+
+def test_cost_fp16_input_close_to_fp32_oracle():
+    """fp16 QK storage is a build-side extension (the reference only sees fp32):
+    quantify against the fp32 oracle on the same (fp16-rounded) logits."""
+    heads = list(range(6))
+    q = synth.synth_qk(7, 6, 20, lo=100, hi=400).astype(np.float16).astype(np.float32)
+    got = run_cost([q], heads, [(100, 400)], [-1], dtype=torch.float16)[0]
+    ref = oracle_cost(q, heads, (100, 400), -1)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("case", json.load(open(os.path.join(G, "align_cases.json"), encoding="utf-8")),
+                         ids=lambda c: c["name"])
+def test_perform_word_alignment_matches_reference_fixture(case):
+    """The drop-in perform_word_alignment on the GPU vs the words the reference's
+    own code produced (tests/golden/make_golden.py)."""
+    import whisper_timestamped as wt
+    tokens, att, heads, mfcc, tok = build_case_inputs(case)
+    ah = None if heads is None else np.array(heads)
+    words = wt.perform_word_alignment(
+        tokens, [a.to(DEV) for a in att], tok, use_space=case.get("use_space", True),
+        mfcc=None if mfcc is None else mfcc.to(DEV), refine_whisper_precision_nframes=case["refine"],
+        remove_punctuation_from_words=case.get("remove_punct", False), alignment_heads=ah,
+        detect_disfluencies=case.get("disfl", False))
+    exp = case["words"]
+    assert [w["text"] for w in words] == [w["text"] for w in exp]
+    assert [w["tokens"] for w in words] == [w["tokens"] for w in exp]
+    assert [[int(x) for x in w["tokens_indices"]] for w in words] == [w["tokens_indices"] for w in exp]
+    dt = max([0.0] + [max(abs(a["start"] - b["start"]), abs(a["end"] - b["end"])) for a, b in zip(words, exp)])
+    assert dt <= 0.02 + 1e-9, dt
+
+
+def test_batch_of_real_shapes_vs_oracle():
+    """160 units with the T/F mix measured on the reference goldens, one
+    launch set; jumps compared with the oracle run on the oracle's own cost."""
+    import whisper_timestamped as wt
+    from whisper_timestamped.alignment import AlignmentBatch, AlignmentUnit
+    tok = synth.StubTokenizer()
+    Ts, Fs = synth.draw_real_shapes(5, 160)
+    heads = [25, 34, 35, 39, 41, 42, 44, 46]
+    batch = AlignmentBatch(keep_cost=True)
+    refs = []
+    rng = np.random.RandomState(9)
+    for k, (T, F) in enumerate(zip(Ts, Fs)):
+        T, F = int(T), int(F)
+        s = int(rng.randint(0, 1500 - F + 1))
+        q = synth.synth_qk(1000 + k, 48, T, lo=s, hi=s + F)
+        sel = torch.from_numpy(q[heads])
+        pad = -1 if k % 16 else int(rng.randint(F // 2, F))
+        refs.append(O.cost_matrix_ref(sel[:, :, s:s + F], 9, 1.0, pad if pad >= 0 else None, 0))
+        batch.add(AlignmentUnit(tokens=[0] * T, qk=sel.to(DEV).contiguous(), start_token=s, end_token=s + F, pad_from=pad,
+                                words=[], word_pieces=[], word_ids=[], punct_counts=[], refine_nframes=25,
+                                unfinished_decoding=False, detect_disfluencies=False, tokenizer=tok))
+    # run only the device part
+    import whisper_timestamped.alignment as A
+    orig = A.finish_unit
+    A.finish_unit = lambda u, j, c=None: j
+    try:
+        jumps = batch.run()
+    finally:
+        A.finish_unit = orig
+    worst = 0
+    for k, (jm, ref) in enumerate(zip(jumps, refs)):
+        r = O.dtw_ref(ref)
+        want = O.jumps_from_path(r.index1s, r.index2s)
+        worst = max(worst, int(np.abs(jm - want).max()))
+        # and bit-exact when the oracle DTW is fed the GPU's own cost
+        g = batch.unit_cost(k).cpu().numpy().astype(np.float64)
+        r2 = O.dtw_ref(g)
+        assert np.array_equal(jm, O.jumps_from_path(r2.index1s, r2.index2s))
+    print(f"max |jump difference| vs oracle end-to-end over 160 units: {worst} frame(s)")
+    assert worst <= 1
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] size: 32 units of (8 heads, 224 tokens, 1500 frames).
+    Size-independent properties + spot parity on 2 units."""
+    L = _lib()
+    n, T, F, A = 32, 224, 1500, 8
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    qk = torch.randn((n, A, T, F), generator=g, dtype=torch.float32)
+    for b in range(n):
+        stairs = np.sort(np.random.RandomState(b).randint(0, F, size=T))
+        for t in range(T):
+            qk[b, :, t, max(stairs[t] - 1, 0):stairs[t] + 2] += 6.0
+    qk_d = qk.to(DEV)
+    descs = L.make_descs(n)
+    for b, d in enumerate(descs):
+        d["qk_offset"], d["head_stride"], d["row_stride"] = b * A * T * F, T * F, F
+        d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, 0, -1
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    dd = L.descs_to_device(descs, DEV)
+    cost = torch.empty(n_cost, device=DEV)
+    jumps = torch.empty(n_jumps, dtype=torch.int32, device=DEV)
+    pi = torch.empty(n_path, dtype=torch.int32, device=DEV)
+    pj = torch.empty(n_path, dtype=torch.int32, device=DEV)
+    pl = torch.empty(n, dtype=torch.int32, device=DEV)
+    dist = torch.empty(n, dtype=torch.float64, device=DEV)
+    L.align_batch(qk_d, descs, dd, torch.arange(A, dtype=torch.int32, device=DEV), cost, jumps, pi, pj, pl, dist)
+    torch.cuda.synchronize()
+    cost_h, jm, pi, pj, pl, dist = cost.cpu().numpy(), jumps.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), \
+        pl.cpu().numpy(), dist.cpu().numpy()
+    for b, d in enumerate(descs):
+        c = cost_h[d["cost_offset"]:d["cost_offset"] + T * F].reshape(T, F)
+        j = jm[d["jumps_offset"]:d["jumps_offset"] + T + 1]
+        assert j[0] == 0 and j[-1] == F - 1 and (np.diff(j) >= 0).all()
+        # columns of -cost have unit L2 norm (except the overwritten [0,0])
+        nrm = np.sqrt((c.astype(np.float64)[:, 1:] ** 2).sum(0))
+        assert np.abs(nrm - 1).max() < 1e-5
+        p1, p2 = pi[d["path_offset"]:d["path_offset"] + pl[b]], pj[d["path_offset"]:d["path_offset"] + pl[b]]
+        assert (p1[0], p2[0]) == (0, 0) and (p1[-1], p2[-1]) == (T - 1, F - 1)
+        steps = set(zip(np.diff(p1).tolist(), np.diff(p2).tolist()))
+        assert steps <= {(1, 1), (0, 1), (1, 0)}
+        acc = 0.0
+        for a, bb in zip(p1, p2):
+            acc = float(c[a, bb]) if (a, bb) == (0, 0) else acc + float(c[a, bb])
+        assert acc == dist[b]
+        # the ridge is recovered: most tokens within a few frames of their staircase position
+        stairs = np.sort(np.random.RandomState(b).randint(0, F, size=T))
+        assert np.median(np.abs(j[:-1] - stairs)) <= 3
+    for b in (0, 31):
+        d = descs[b]
+        ref = O.cost_matrix_ref(qk[b], 9, 1.0, None, 0)
+        c = cost_h[d["cost_offset"]:d["cost_offset"] + T * F].reshape(T, F)
+        assert np.abs(c - ref).max() / np.abs(ref).max() < 2e-6
+        r = O.dtw_ref(c.astype(np.float64))
+        assert np.array_equal(jm[d["jumps_offset"]:d["jumps_offset"] + T + 1], O.jumps_from_path(r.index1s, r.index2s))
+
+
+# ---------------------------------------------------------------------------
+def test_logprob_gather_vs_oracle():
+    L = _lib()
+    rng = np.random.RandomState(4)
+    for V, n in [(51865, 40), (51864, 7), (51866, 5), (1000, 3), (7, 2)]:
+        logits = (rng.standard_normal((n, V)) * 4).astype(np.float32)
+        toks = rng.randint(0, V, size=n).astype(np.int32)
+        got = L.logprob_gather(torch.from_numpy(logits).to(DEV), torch.from_numpy(toks)).cpu()
+        want = O.token_logprob_gather_ref(torch.from_numpy(logits), toks)
+        assert (got - want).abs().max() < 2e-5, (V, (got - want).abs().max())
+        # with a suppression mask (the logit filters' -inf), shared and per-row
+        mask = rng.rand(V) < 0.3
+        mask[toks] = False
+        got = L.logprob_gather(torch.from_numpy(logits).to(DEV), torch.from_numpy(toks), torch.from_numpy(mask)).cpu()
+        want = O.token_logprob_gather_ref(torch.from_numpy(logits), toks, np.broadcast_to(mask, (n, V)).copy())
+        assert (got - want).abs().max() < 2e-5
+        maskn = rng.rand(n, V) < 0.5
+        maskn[np.arange(n), toks] = False
+        got = L.logprob_gather(torch.from_numpy(logits).to(DEV), torch.from_numpy(toks), torch.from_numpy(maskn)).cpu()
+        want = O.token_logprob_gather_ref(torch.from_numpy(logits), toks, maskn)
+        assert (got - want).abs().max() < 2e-5
+    # confidence = exp(mean(logprobs)) within 1e-4 before rounding
+    lp_g, lp_o = got.numpy(), want.numpy()
+    assert abs(np.exp(lp_g.mean()) - O.confidence_raw_ref(lp_o)) < 1e-4
+
+
+def test_logprob_gather_strided_rows_and_suppressed_token():
+    L = _lib()
+    rng = np.random.RandomState(5)
+    big = torch.from_numpy(rng.standard_normal((6, 3, 5000)).astype(np.float32)).to(DEV)
+    rows = big[:, 1, :]                                   # row stride 15000, unaligned starts
+    toks = torch.tensor([0, 4999, 17, 3, 2500, 1], dtype=torch.int32)
+    got = L.logprob_gather(rows, toks).cpu()
+    want = O.token_logprob_gather_ref(rows.cpu(), toks.numpy())
+    assert (got - want).abs().max() < 2e-5
+    mask = torch.zeros(5000, dtype=torch.bool)
+    mask[17] = True
+    got = L.logprob_gather(rows, toks, mask).cpu()
+    assert got[2] == -np.inf and torch.isfinite(got[[0, 1, 3, 4, 5]]).all()
+
+
+def test_find_start_padding_fixture_and_random():
+    L = _lib()
+    mels, exp = [], []
+    for p in json.load(open(os.path.join(G, "find_start_padding.json"))):
+        if p["n_mels"] != 80:
+            continue
+        rng = np.random.RandomState(p["seed"])
+        m = rng.standard_normal((1, p["n_mels"], 3000)).astype(np.float32)
+        if p["kind"] in ("zeros", "zero_col_inside"):
+            m[..., p["col"]:] = 0.0
+            if p["kind"] == "zero_col_inside":
+                m[..., 1000] = 0.0
+        elif p["kind"] == "allzero":
+            m[:] = 0.0
+        elif p["kind"] == "const_nonzero":
+            m[..., p["col"]:] = 0.5
+        mels.append(m[0])
+        exp.append(-1 if p["expected"] is None else p["expected"])
+    rng = np.random.RandomState(6)
+    for _ in range(20):
+        m = rng.standard_normal((80, 3000)).astype(np.float32)
+        c = int(rng.randint(0, 3001))
+        m[:, c:] = 0.0
+        if rng.rand() < 0.3:
+            m[:, -1] = -0.0
+        mels.append(m)
+        r = O.find_start_padding_ref(torch.from_numpy(m[None]))
+        exp.append(-1 if r is None else r)
+    got = L.find_start_padding(torch.from_numpy(np.stack(mels)).to(DEV)).cpu().tolist()
+    assert got == exp
+    m128 = np.zeros((2, 128, 3000), np.float32)
+    m128[0, 5, :1] = 1.0
+    m128[1, 127, :2999] = 1.0
+    assert L.find_start_padding(torch.from_numpy(m128).to(DEV)).cpu().tolist() == [0, 2999]
+
+
+def test_logmel_vs_oracle():
+    L = _lib()
+    rng = np.random.RandomState(7)
+    n = 480000
+    pcm = (0.1 * rng.standard_normal((3, n))).astype(np.float32)
+    t = np.arange(n) / 16000.0
+    pcm[1] += (0.3 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    valid = np.array([n, n, 16000 * 7 + 77], dtype=np.int32)
+    pcm[2, valid[2]:] = 0.0
+    for n_mels in (80, 128):
+        fb = O.mel_filters_ref(n_mels)
+        mel, gmax = L.logmel(torch.from_numpy(pcm).to(DEV), fb, torch.from_numpy(valid))
+        mel = mel.cpu()
+        for b in range(3):
+            ref = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(torch.from_numpy(pcm[b, :valid[b]]), n_mels), 3000)
+            err = (mel[b] - ref).abs().max().item()
+            assert err < 2e-4, (n_mels, b, err)
+        # exact zeros in the padding, so that find_start_padding sees it
+        assert (mel[2][:, valid[2] // 160:] == 0).all()
+        assert L.find_start_padding(mel.to(DEV)).cpu().tolist()[2] == valid[2] // 160

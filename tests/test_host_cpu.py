@@ -1,0 +1,116 @@
+"""CPU tests: the C-ABI library loads and exports every symbol of
+include/wtalign.h; the host-side (Python) part of the path reproduces the
+reference's known answers and the fixtures generated from the reference."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import align_ref as O
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from whisper_timestamped import _lib
+    hdr = open(os.path.join(ROOT, "include", "wtalign.h")).read()
+    declared = sorted(set(re.findall(r"\b(wt_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    L.wt_version.restype = ctypes.c_int
+    assert L.wt_version() == 1
+
+
+def test_seg_desc_layout_matches_header():
+    from whisper_timestamped import _lib
+    assert _lib.SEG_DTYPE.itemsize == 64
+    assert [_lib.SEG_DTYPE.fields[n][1] for n in ("qk_offset", "head_stride", "row_stride", "cost_offset",
+                                                    "jumps_offset", "path_offset", "T", "F", "start_token",
+                                                    "pad_from")] == [0, 8, 16, 24, 32, 40, 48, 52, 56, 60]
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from whisper_timestamped import _lib
+    with pytest.raises(_lib.WtError):
+        _lib.find_start_padding(torch.zeros(1, 80, 3000))
+
+
+def test_split_tokens_kat():
+    from whisper_timestamped.words import split_tokens_on_spaces
+    for k in json.load(open(os.path.join(G, "split_tokens_kat.json"), encoding="utf-8")):
+        tok = synth.StubTokenizer(multilingual=k["multilingual"])
+        got = split_tokens_on_spaces(list(k["tokens"]), tok)
+        assert got == (k["words"], k["word_tokens"], k["word_tokens_indices"]), k["source"]
+
+
+def test_split_tokens_random_vs_oracle():
+    from whisper_timestamped.words import split_tokens_on_spaces, split_tokens_on_unicode
+    tok = synth.StubTokenizer()
+    rng = np.random.RandomState(11)
+    for _ in range(300):
+        n = rng.randint(1, 40)
+        toks = [tok.timestamp_begin + int(rng.randint(0, 700))] + rng.randint(0, 50257, size=n).tolist()
+        if rng.rand() < 0.8:
+            toks.append(tok.timestamp_begin + int(rng.randint(700, 1500)))
+        for rm in (False, True):
+            try:
+                want = O.split_tokens_on_spaces_ref(list(toks), tok, rm)
+            except IndexError:
+                with pytest.raises(IndexError):
+                    split_tokens_on_spaces(list(toks), tok, rm)
+                continue
+            assert split_tokens_on_spaces(list(toks), tok, rm) == want
+            assert split_tokens_on_unicode(list(toks), tok, rm) == O.split_tokens_on_unicode_ref(list(toks), tok, rm)
+
+
+def test_frame_window_vs_oracle():
+    from whisper_timestamped.words import frame_window
+    rng = np.random.RandomState(12)
+    tb = 50364
+    for _ in range(2000):
+        n = rng.randint(2, 60)
+        toks = [tb + int(rng.randint(-2, 1501))] + rng.randint(0, 50000, size=n - 2).tolist() + \
+               [int(rng.choice([tb + int(rng.randint(0, 1501)), 50257, tb + int(rng.randint(0, 40))]))]
+        refine = int(rng.choice([0, 25]))
+        try:
+            want = O.frame_window_ref(toks, tb, refine)
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                frame_window(toks, tb, refine)
+            continue
+        assert frame_window(toks, tb, refine) == want
+
+
+def test_words_from_fixture_jumps():
+    """Host half of the path on the reference-generated fixtures: feed the
+    fixture's DTW path, expect the fixture's words."""
+    from whisper_timestamped import words as W
+    from golden.make_golden import build_case_inputs
+    cases = json.load(open(os.path.join(G, "align_cases.json"), encoding="utf-8"))
+    for c in cases:
+        if c.get("disfl"):
+            continue
+        tokens, att, heads, mfcc, tok = build_case_inputs(c)
+        T, F = c["cost_shape"]
+        unfinished = False
+        if len(tokens) > T:              # the reference truncated (transcribe.py:1516-1535)
+            tokens = tokens[:T - 1] + [tokens[-1]]
+            unfinished = True
+        win = W.frame_window(tokens, tok.timestamp_begin, c["refine"])
+        assert win[1] - win[0] == F
+        split = W.split_tokens_on_spaces if c.get("use_space", True) else W.split_tokens_on_unicode
+        words, pieces, ids = split(tokens, tok, remove_punctuation_from_words=c.get("remove_punct", False))
+        jumps = O.jumps_from_path(np.array(c["index1s"]), np.array(c["index2s"]))
+        got = W.words_from_jumps(jumps, jumps, words, pieces, ids, W.trailing_punctuation_counts(pieces),
+                                 win[0] * W.AUDIO_TIME_PER_TOKEN, c["refine"], unfinished)
+        got = [dict(text=w["text"], start=w["start"], end=w["end"], tokens=w["tokens"],
+                    tokens_indices=[int(x) for x in w["tokens_indices"]]) for w in got]
+        assert got == c["words"], c["name"]

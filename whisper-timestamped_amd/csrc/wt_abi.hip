@@ -1,0 +1,124 @@
+// extern "C" surface of libwtalign.so (see include/wtalign.h) + host plumbing.
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "wt_common.h"
+
+namespace wt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return WT_E_HIP;
+}
+
+struct Arena {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+static std::mutex g_mu;
+static std::map<std::pair<int, int>, Arena> g_arena;  // per (device, purpose)
+
+// Growing is a hipMalloc (synchronising, not graph-capturable); the first call
+// reserves enough for 64K units so that steady state never grows.
+static int scratch_ex(int purpose, size_t bytes, void **out) {
+    int dev = 0;
+    WT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    Arena &a = g_arena[std::make_pair(dev, purpose)];
+    if (bytes > a.cap) {
+        size_t want = bytes < (256u << 10) ? (256u << 10) : bytes * 2;
+        void *np = nullptr;
+        WT_HIP(hipMalloc(&np, want));
+        if (a.p) {
+            WT_HIP(hipDeviceSynchronize());
+            WT_HIP(hipFree(a.p));
+        }
+        a.p = np;
+        a.cap = want;
+    }
+    *out = a.p;
+    return WT_OK;
+}
+int scratch(size_t bytes, void **out) { return scratch_ex(0, bytes, out); }   // cost path
+int scratch2(size_t bytes, void **out) { return scratch_ex(1, bytes, out); }  // log-mel path
+
+int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, int, float, float *,
+               hipStream_t);
+int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int32_t *, int32_t *, int32_t *, int32_t *,
+              double *, hipStream_t);
+int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, float *, hipStream_t);
+int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
+int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
+
+}  // namespace wt
+
+extern "C" {
+
+int wt_version(void) { return WT_ABI_VERSION; }
+
+const char *wt_last_error(void) { return wt::g_err; }
+
+int wt_shutdown(void) {
+    std::lock_guard<std::mutex> lk(wt::g_mu);
+    for (auto &kv : wt::g_arena) {
+        if (kv.second.p) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(kv.first.first);
+            (void)hipFree(kv.second.p);
+            (void)hipSetDevice(cur);
+        }
+    }
+    wt::g_arena.clear();
+    return WT_OK;
+}
+
+int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                  const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, void *stream) {
+    return wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost,
+                          (hipStream_t)stream);
+}
+
+int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
+                 int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream) {
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, jumps, path_i, path_j, path_len, dist, (hipStream_t)stream);
+}
+
+int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                   const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
+                   int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream) {
+    int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost,
+                            (hipStream_t)stream);
+    if (rc) return rc;
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, jumps, path_i, path_j, path_len, dist, (hipStream_t)stream);
+}
+
+int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, void *stream) {
+    return wt::find_start_padding_batch(mel, n_chunks, n_mels, n_cols, out, (hipStream_t)stream);
+}
+
+int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
+                            const int32_t *token, const uint8_t *suppress, int suppress_rows, float *out, void *stream) {
+    return wt::logprob_gather_batch(logits, logits_dtype, row_stride, n_rows, V, token, suppress, suppress_rows, out,
+                                    (hipStream_t)stream);
+}
+
+int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
+                    int n_mels, int n_frames, float *mel_out, float *gmax, void *stream) {
+    return wt::logmel_batch(pcm, n_chunks, n_samples, n_valid_samples, mel_fb, n_mels, n_frames, mel_out, gmax,
+                            (hipStream_t)stream);
+}
+
+}  // extern "C"

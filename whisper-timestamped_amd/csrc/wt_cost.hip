@@ -1,0 +1,251 @@
+// Local-cost construction for the DTW word alignment, batched over units.
+//
+// Replaces the numerics of /root/reference/whisper_timestamped/transcribe.py
+//   :1540-1545  slice frames + select alignment heads
+//   :1546       scipy.ndimage.median_filter(w, (1,1,9))   ('reflect' edges)
+//   :1547       softmax over the F-frame window (* qk_scale first)
+//   :1548       mean over heads
+//   :1549       divide by the per-frame L2 norm over tokens
+//   :1550       negate (the widening to double happens in the DTW kernel)
+//   :1561-1565  padding mask (absolute-index quirk carried by wt_seg_desc.pad_from)
+//   :1568       cost[0,0] = cost.min()
+//
+// Kernel 1 (rowmean): ONE WAVE per (unit, token row).  For each selected head
+//   the row (F <= 1792 fp32 logits) is read once from HBM with coalesced
+//   dword loads, staged in LDS, re-read as one contiguous chunk per lane (+4
+//   halo each side, ds_read_b128, chunk stride chosen bank-conflict-free), and
+//   everything else happens in registers: median-of-9 with the 3x3
+//   sorted-column identity on v_min3/v_med3/v_max3 (7 VALU ops per element),
+//   wave-wide max / sum by cross-lane butterflies, exp, accumulate over heads.
+//   No workgroup barrier anywhere.  Algorithmic HBM bytes: A*T*F*4 read +
+//   T*F*4 written.
+// Kernel 2 (colnorm): per 64-column tile, column sum of squares over tokens
+//   (f64 accumulate), in-place normalise/negate/mask, per-unit min via one
+//   atomicMax on the magnitude bits.  Kernel 3 (fix00): cost[0,0] = min.
+#include <hip/hip_fp16.h>
+
+#include "wt_common.h"
+
+namespace wt {
+
+__device__ __forceinline__ float ld_qk(const float *p) { return *p; }
+__device__ __forceinline__ float ld_qk(const __half *p) { return __half2float(*p); }
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// C = elements per lane (4,12,20,28: C/4 odd => conflict-free ds_read_b128).
+template <int C, typename QT>
+__global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
+                                                      const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
+                                                      float *__restrict__ cost) {
+    constexpr int CAP = C * 64;
+    constexpr int FLO = (C == 4) ? 0 : (C - 8) * 64;  // this instantiation serves FLO < F <= CAP
+    __shared__ __attribute__((aligned(16))) float lds[4][CAP + 8];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const wt_seg_desc d = segs[blockIdx.y];
+    const int F = d.F;
+    const int t = blockIdx.x * 4 + wave;
+    if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
+
+    float *xs = lds[wave];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+    const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
+
+    // halo duty of lanes 0..7 (source index inside the row)
+    const int hpos = lane < 4 ? -(lane + 1) : F + (lane - 4);
+    const int hsrc = reflect_index(hpos, F);
+
+    float acc[C];
+#pragma unroll
+    for (int q = 0; q < C; ++q) acc[q] = 0.f;
+
+    for (int a = 0; a < n_heads; ++a) {
+        const QT *src = row0 + (int64_t)head_idx[a] * d.head_stride;
+        float v[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = k * 64 + lane;
+            v[k] = (f < F) ? ld_qk(src + f) : 0.f;
+        }
+        const float hv = (lane < 8) ? ld_qk(src + hsrc) : 0.f;
+
+        wave_lds_fence();  // previous head's LDS reads are done (WAR)
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int f = k * 64 + lane;
+            if (f < F) xs[4 + f] = v[k];
+        }
+        if (lane < 8) xs[4 + hpos] = hv;
+        wave_lds_fence();
+
+        float x[C + 8];
+        const float4 *xp = reinterpret_cast<const float4 *>(xs + lane * C);
+#pragma unroll
+        for (int k = 0; k < (C + 8) / 4; ++k) {
+            const float4 r = xp[k];
+            x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
+        }
+        // sorted triples (lo,mid,hi) of (x[p],x[p+1],x[p+2])
+        float lo[C + 6], mi[C + 6], hi[C + 6];
+#pragma unroll
+        for (int p = 0; p < C + 6; ++p) {
+            lo[p] = min3f(x[p], x[p + 1], x[p + 2]);
+            mi[p] = med3f(x[p], x[p + 1], x[p + 2]);
+            hi[p] = max3f(x[p], x[p + 1], x[p + 2]);
+        }
+        float m[C];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const float med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
+                                    min3f(hi[q], hi[q + 3], hi[q + 6]));
+            const bool ok = (lane * C + q) < F;
+            m[q] = ok ? med * qk_scale : -INFINITY;
+            mx = fmaxf(mx, m[q]);
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            m[q] = expf(m[q] - mx);
+            s += m[q];
+        }
+        s = wave_sum(s);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int q = 0; q < C; ++q) acc[q] += m[q] * inv;
+    }
+
+    // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
+    const float nh = (float)n_heads;
+    wave_lds_fence();
+    float4 *op = reinterpret_cast<float4 *>(xs + lane * C);
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k)
+        op[k] = make_float4(acc[4 * k] / nh, acc[4 * k + 1] / nh, acc[4 * k + 2] / nh, acc[4 * k + 3] / nh);
+    wave_lds_fence();
+    float *out = cost + d.cost_offset + (int64_t)t * F;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int f = k * 64 + lane;
+        if (f < F) out[f] = xs[f];
+    }
+}
+
+__global__ __launch_bounds__(256) void colnorm_kernel(float *__restrict__ cost, const wt_seg_desc *__restrict__ segs,
+                                                      unsigned *__restrict__ segmax) {
+    const wt_seg_desc d = segs[blockIdx.y];
+    const int F = d.F, T = d.T;
+    if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
+    __shared__ double ssq[4][64];
+    __shared__ float smx[4][64];
+    __shared__ float snorm[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + lane;
+    const bool valid = f < F;
+    const bool masked_col = d.pad_from >= 0 && f >= d.pad_from;
+    float *base = cost + d.cost_offset;
+
+    double ss = 0.0;
+    float mx = 0.f;
+    for (int t = wave; t < T; t += 4) {
+        const float v = valid ? base[(int64_t)t * F + f] : 0.f;
+        ss += (double)v * (double)v;
+        if (!masked_col || t == T - 1) mx = fmaxf(mx, v);
+    }
+    ssq[wave][lane] = ss;
+    smx[wave][lane] = mx;
+    __syncthreads();
+    if (wave == 0) {
+        const double tot = (ssq[0][lane] + ssq[1][lane]) + (ssq[2][lane] + ssq[3][lane]);
+        const float norm = sqrtf((float)tot);
+        snorm[lane] = norm;
+        float m = fmaxf(fmaxf(smx[0][lane], smx[1][lane]), fmaxf(smx[2][lane], smx[3][lane]));
+        float r = valid ? m / norm : 0.f;  // max_t(w/norm) == max_t(w)/norm: IEEE division is monotone
+        r = wave_max(r);
+        if (lane == 0) atomicMax(segmax + blockIdx.y, __float_as_uint(r));
+    }
+    __syncthreads();
+    const float norm = snorm[lane];
+    if (valid) {
+        for (int t = wave; t < T; t += 4) {
+            float *p = base + (int64_t)t * F + f;
+            const float v = *p;
+            *p = (masked_col && t < T - 1) ? 0.f : -(v / norm);
+        }
+    }
+}
+
+__global__ void fix00_kernel(float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, const unsigned *__restrict__ segmax,
+                             int n_seg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_seg) cost[segs[s].cost_offset] = -__uint_as_float(segmax[s]);
+}
+
+template <typename QT>
+static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                          const int32_t *head_idx, int n_heads, float qk_scale, float *cost, hipStream_t st) {
+    int maxT[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n_seg; ++i) {
+        const int F = segs_host[i].F;
+        const int c = F <= 256 ? 0 : F <= 768 ? 1 : F <= 1280 ? 2 : 3;
+        if (segs_host[i].T > maxT[c]) maxT[c] = segs_host[i].T;
+    }
+#define WT_LAUNCH_ROWMEAN(CI, CC)                                                                                   \
+    if (maxT[CI] > 0) {                                                                                             \
+        dim3 grid((maxT[CI] + 3) / 4, n_seg);                                                                       \
+        hipLaunchKernelGGL((rowmean_kernel<CC, QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, n_heads,       \
+                           qk_scale, cost);                                                                         \
+    }
+    WT_LAUNCH_ROWMEAN(0, 4)
+    WT_LAUNCH_ROWMEAN(1, 12)
+    WT_LAUNCH_ROWMEAN(2, 20)
+    WT_LAUNCH_ROWMEAN(3, 28)
+#undef WT_LAUNCH_ROWMEAN
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+               const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, hipStream_t st) {
+    if (!qk || !segs_host || !segs_dev || !head_idx || !cost || n_seg < 0 || n_heads <= 0) {
+        set_error("wt_cost_batch: null pointer or bad count");
+        return WT_E_BADARG;
+    }
+    if (n_seg == 0) return WT_OK;
+    if (medfilt_width != 9) {
+        set_error("wt_cost_batch: medfilt_width=%d unsupported (the reference always uses 9)", medfilt_width);
+        return WT_E_UNSUPPORTED;
+    }
+    int maxF = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        const wt_seg_desc &d = segs_host[i];
+        if (d.T < 1 || d.F < 1 || d.F > WT_MAX_FRAMES || d.start_token < 0) {
+            set_error("wt_cost_batch: unit %d has unsupported shape T=%d F=%d start=%d", i, d.T, d.F, d.start_token);
+            return WT_E_UNSUPPORTED;
+        }
+        if (d.F > maxF) maxF = d.F;
+    }
+    unsigned *segmax = nullptr;
+    int rc = scratch((size_t)n_seg * sizeof(unsigned), (void **)&segmax);
+    if (rc) return rc;
+    WT_HIP(hipMemsetAsync(segmax, 0, (size_t)n_seg * sizeof(unsigned), st));
+    if (qk_dtype == WT_DTYPE_F32)
+        rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, st);
+    else if (qk_dtype == WT_DTYPE_F16)
+        rc = launch_rowmean((const __half *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, st);
+    else {
+        set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
+        return WT_E_BADARG;
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(256), 0, st, cost, segs_dev, segmax);
+    hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segmax, n_seg);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+}  // namespace wt

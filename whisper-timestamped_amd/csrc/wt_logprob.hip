@@ -1,0 +1,193 @@
+// Confidence path: chosen-token log-probability of each decode step, and the
+// padding detector.
+//
+// logprob_gather replaces /root/reference/whisper_timestamped/transcribe.py
+//   :871-876  logits -> (logit filters write -inf) -> F.log_softmax(dim=-1)
+//   :735      logprob[tok] gather                      (efficient strategy)
+//   :1245     F.log_softmax(logits, dim=-1); :1292 logprobs[:, step, tok]  (naive)
+// without materialising the (n_rows, V) log-prob matrix: one workgroup per
+// row streams the V logits ONCE from HBM (16-byte loads on the aligned body),
+// keeps a running (max, sum-of-exp) pair per thread, merges the pairs across
+// the workgroup and writes a single float.  Algorithmic bytes: V*4 per row.
+//
+// find_start_padding replaces transcribe.py:1795-1805.
+#include <hip/hip_fp16.h>
+
+#include "wt_common.h"
+
+namespace wt {
+
+struct MS {  // running max / sum of exp(x - max)
+    float m, s;
+};
+__device__ __forceinline__ void ms_add4(MS &a, float x0, float x1, float x2, float x3) {
+    const float cm = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    if (cm == -INFINITY) return;
+    if (cm > a.m) {
+        a.s *= expf(a.m - cm);  // a.m == -inf -> exp(-inf) = 0
+        a.m = cm;
+    }
+    a.s += (expf(x0 - a.m) + expf(x1 - a.m)) + (expf(x2 - a.m) + expf(x3 - a.m));
+}
+__device__ __forceinline__ void ms_add1(MS &a, float x) {
+    if (x == -INFINITY) return;
+    if (x > a.m) {
+        a.s *= expf(a.m - x);
+        a.m = x;
+    }
+    a.s += expf(x - a.m);
+}
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+    if (b.m == -INFINITY) return a;
+    if (a.m == -INFINITY) return b;
+    MS r;
+    r.m = fmaxf(a.m, b.m);
+    r.s = a.s * expf(a.m - r.m) + b.s * expf(b.m - r.m);
+    return r;
+}
+
+__device__ __forceinline__ float ldf(const float *p) { return *p; }
+__device__ __forceinline__ float ldf(const __half *p) { return __half2float(*p); }
+
+template <typename LT>
+__global__ __launch_bounds__(256) void logprob_gather_kernel(const LT *__restrict__ logits, int64_t row_stride, int V,
+                                                             const int32_t *__restrict__ token,
+                                                             const uint8_t *__restrict__ suppress, int suppress_rows,
+                                                             float *__restrict__ out) {
+    const int row = blockIdx.x;
+    const LT *x = logits + (int64_t)row * row_stride;
+    const uint8_t *sup = suppress ? suppress + (suppress_rows > 1 ? (int64_t)row * V : 0) : nullptr;
+    const int tid = threadIdx.x;
+    MS acc = {-INFINITY, 0.f};
+
+    constexpr int VEC = 16 / sizeof(LT);  // elements per 16-byte load
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+    int head = (int)(((16 - (addr & 15)) & 15) / sizeof(LT));
+    if (head > V) head = V;
+    const int nvec = (V - head) / VEC;
+    const int tail0 = head + nvec * VEC;
+
+    if (tid < head) ms_add1(acc, (sup && sup[tid]) ? -INFINITY : ldf(x + tid));
+    if (tid < V - tail0) {
+        const int e = tail0 + tid;
+        ms_add1(acc, (sup && sup[e]) ? -INFINITY : ldf(x + e));
+    }
+    if constexpr (sizeof(LT) == 4) {
+        const float4 *xv = reinterpret_cast<const float4 *>(x + head);
+        for (int v = tid; v < nvec; v += 256) {
+            float4 r = xv[v];
+            if (sup) {
+                const uint8_t *sp = sup + head + 4 * v;
+                if (sp[0]) r.x = -INFINITY;
+                if (sp[1]) r.y = -INFINITY;
+                if (sp[2]) r.z = -INFINITY;
+                if (sp[3]) r.w = -INFINITY;
+            }
+            ms_add4(acc, r.x, r.y, r.z, r.w);
+        }
+    } else {
+        const uint4 *xv = reinterpret_cast<const uint4 *>(x + head);
+        for (int v = tid; v < nvec; v += 256) {
+            const uint4 raw = xv[v];
+            const __half2 *h = reinterpret_cast<const __half2 *>(&raw);
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float2 t = __half22float2(h[k]);
+                f[2 * k] = t.x;
+                f[2 * k + 1] = t.y;
+            }
+            if (sup) {
+                const uint8_t *sp = sup + head + 8 * v;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (sp[k]) f[k] = -INFINITY;
+            }
+            ms_add4(acc, f[0], f[1], f[2], f[3]);
+            ms_add4(acc, f[4], f[5], f[6], f[7]);
+        }
+    }
+    // wave butterfly, then across the 4 waves through LDS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MS b;
+        b.m = __shfl_xor(acc.m, o, 64);
+        b.s = __shfl_xor(acc.s, o, 64);
+        acc = ms_merge(acc, b);
+    }
+    __shared__ MS part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        MS t = ms_merge(ms_merge(part[0], part[1]), ms_merge(part[2], part[3]));
+        const int tok = token[row];
+        float xt = -INFINITY;
+        if (tok >= 0 && tok < V && !(sup && sup[tok])) xt = ldf(x + tok);
+        out[row] = (xt - t.m) - logf(t.s);
+    }
+}
+
+int logprob_gather_batch(const void *logits, int dtype, int64_t row_stride, int n_rows, int V, const int32_t *token,
+                         const uint8_t *suppress, int suppress_rows, float *out, hipStream_t st) {
+    if (!logits || !token || !out || n_rows < 0 || V <= 0 || row_stride < V ||
+        (suppress && suppress_rows != 1 && suppress_rows != n_rows)) {
+        set_error("wt_logprob_gather_batch: bad argument");
+        return WT_E_BADARG;
+    }
+    if (n_rows == 0) return WT_OK;
+    const uint8_t *sup = suppress_rows > 0 ? suppress : nullptr;
+    if (dtype == WT_DTYPE_F32)
+        hipLaunchKernelGGL(logprob_gather_kernel<float>, dim3(n_rows), dim3(256), 0, st, (const float *)logits, row_stride, V,
+                           token, sup, suppress_rows, out);
+    else if (dtype == WT_DTYPE_F16)
+        hipLaunchKernelGGL(logprob_gather_kernel<__half>, dim3(n_rows), dim3(256), 0, st, (const __half *)logits, row_stride,
+                           V, token, sup, suppress_rows, out);
+    else {
+        set_error("wt_logprob_gather_batch: dtype=%d", dtype);
+        return WT_E_BADARG;
+    }
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// transcribe.py:1795-1805.  One workgroup per (n_mels, n_cols) window; thread
+// c-strided over columns so every mel row is read coalesced.
+__global__ __launch_bounds__(256) void find_start_padding_kernel(const float *__restrict__ mel, int n_mels, int n_cols,
+                                                                 int32_t *__restrict__ out) {
+    const float *m = mel + (int64_t)blockIdx.x * n_mels * n_cols;
+    const int tid = threadIdx.x;
+    int last_nz = 0;  // highest column in [1, n_cols-2] holding a value != 0
+    int tail_nz = 0;  // last column not all-zero?
+    for (int c = tid; c < n_cols; c += 256) {
+        bool nz = false;
+        for (int r = 0; r < n_mels; ++r) nz |= !(m[(int64_t)r * n_cols + c] == 0.f);
+        if (nz) {
+            if (c == n_cols - 1) tail_nz = 1;
+            else if (c >= 1) last_nz = c;  // c ascending per thread
+        }
+    }
+    last_nz = wave_max_i(last_nz);
+    tail_nz = wave_max_i(tail_nz);
+    __shared__ int s_last[4], s_tail[4];
+    if ((tid & 63) == 0) { s_last[tid >> 6] = last_nz; s_tail[tid >> 6] = tail_nz; }
+    __syncthreads();
+    if (tid == 0) {
+        const int l = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+        const int t = max(max(s_tail[0], s_tail[1]), max(s_tail[2], s_tail[3]));
+        out[blockIdx.x] = t ? -1 : (l > 0 ? l + 1 : 0);
+    }
+}
+
+int find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, hipStream_t st) {
+    if (!mel || !out || n_chunks < 0 || n_mels <= 0 || n_cols < 2) {
+        set_error("wt_find_start_padding_batch: bad argument");
+        return WT_E_BADARG;
+    }
+    if (n_chunks == 0) return WT_OK;
+    hipLaunchKernelGGL(find_start_padding_kernel, dim3(n_chunks), dim3(256), 0, st, mel, n_mels, n_cols, out);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+}  // namespace wt

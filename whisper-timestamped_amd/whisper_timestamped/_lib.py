@@ -1,0 +1,176 @@
+"""ctypes binding of libwtalign.so (C ABI: include/wtalign.h).
+
+The HIP library is the product path: there is NO CPU fallback.  Importing this
+module without the built library raises; calling into it without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libwtalign.so")
+
+WT_DTYPE_F32, WT_DTYPE_F16 = 0, 1
+WT_MAX_TOKENS, WT_MAX_FRAMES = 256, 1792
+N_AUDIO_CTX = 1500
+
+# mirrors `struct wt_seg_desc` (64 bytes)
+SEG_DTYPE = np.dtype([
+    ("qk_offset", "<i8"), ("head_stride", "<i8"), ("row_stride", "<i8"), ("cost_offset", "<i8"),
+    ("jumps_offset", "<i8"), ("path_offset", "<i8"), ("T", "<i4"), ("F", "<i4"), ("start_token", "<i4"),
+    ("pad_from", "<i4"),
+], align=True)
+assert SEG_DTYPE.itemsize == 64
+
+EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
+           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch"]
+
+
+class WtError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libwtalign.so (raises if it has not been built: `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_PKG_ROOT}/csrc` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    L.wt_version.restype = i32
+    L.wt_last_error.restype = ctypes.c_char_p
+    L.wt_shutdown.restype = i32
+    L.wt_cost_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp]
+    L.wt_dtw_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.wt_align_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
+    L.wt_find_start_padding_batch.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.wt_logprob_gather_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, i32, vp, vp]
+    L.wt_logmel_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp]
+    for n in EXPORTS[3:]:
+        getattr(L, n).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().wt_last_error().decode("utf-8", "replace")
+        raise WtError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(t: torch.Tensor, name: str):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise WtError(f"{name} must be a CUDA(HIP) tensor: the alignment kernels only run on the GPU")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def make_descs(n: int) -> np.ndarray:
+    return np.zeros(n, dtype=SEG_DTYPE)
+
+
+def descs_to_device(descs: np.ndarray, device) -> torch.Tensor:
+    raw = torch.from_numpy(descs.view(np.uint8).reshape(-1))
+    return raw.to(device, non_blocking=False)
+
+
+def layout_outputs(descs: np.ndarray):
+    """Fill cost/jumps/path offsets (cost slots 16-byte aligned). Returns totals."""
+    c = j = p = 0
+    for d in descs:
+        d["cost_offset"], d["jumps_offset"], d["path_offset"] = c, j, p
+        c += (int(d["T"]) * int(d["F"]) + 3) & ~3
+        j += int(d["T"]) + 1
+        p += int(d["T"]) + int(d["F"]) - 1
+    return c, j, p
+
+
+def cost_batch(qk: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, head_idx: torch.Tensor, cost: torch.Tensor,
+               medfilt_width: int = 9, qk_scale: float = 1.0):
+    _need_cuda(qk, "qk")
+    dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[qk.dtype]
+    rc = load().wt_cost_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
+                              head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), _stream())
+    _check(rc, "wt_cost_batch")
+
+
+def dtw_batch(cost: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, jumps: torch.Tensor, path_i=None, path_j=None,
+              path_len=None, dist=None):
+    _need_cuda(cost, "cost")
+    rc = load().wt_dtw_batch(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), len(descs), jumps.data_ptr(),
+                             _ptr(path_i), _ptr(path_j), _ptr(path_len), _ptr(dist), _stream())
+    _check(rc, "wt_dtw_batch")
+
+
+def align_batch(qk, descs, descs_dev, head_idx, cost, jumps, path_i=None, path_j=None, path_len=None, dist=None,
+                medfilt_width: int = 9, qk_scale: float = 1.0):
+    _need_cuda(qk, "qk")
+    dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[qk.dtype]
+    rc = load().wt_align_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
+                               head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), jumps.data_ptr(), _ptr(path_i),
+                               _ptr(path_j), _ptr(path_len), _ptr(dist), _stream())
+    _check(rc, "wt_align_batch")
+
+
+def find_start_padding(mel: torch.Tensor) -> torch.Tensor:
+    """mel: (B, n_mels, n_cols) fp32 on the GPU -> int32[B] (-1 = None)."""
+    _need_cuda(mel, "mel")
+    mel = mel.contiguous()
+    B, M, C = mel.shape
+    out = torch.empty(B, dtype=torch.int32, device=mel.device)
+    _check(load().wt_find_start_padding_batch(mel.data_ptr(), B, M, C, out.data_ptr(), _stream()),
+           "wt_find_start_padding_batch")
+    return out
+
+
+def logprob_gather(logits: torch.Tensor, tokens: torch.Tensor, suppress: torch.Tensor | None = None) -> torch.Tensor:
+    """logits: (n, V) fp32/fp16 (row stride arbitrary, unit column stride); tokens: int32[n];
+    suppress: optional uint8/bool (V,) or (n, V).  Returns fp32[n]."""
+    _need_cuda(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    n, V = logits.shape
+    dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[logits.dtype]
+    tokens = tokens.to(device=logits.device, dtype=torch.int32).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=logits.device)
+    srows, sp = 0, 0
+    if suppress is not None:
+        suppress = suppress.to(device=logits.device).to(torch.uint8).contiguous()
+        srows = 1 if suppress.dim() == 1 else suppress.shape[0]
+        sp = suppress.data_ptr()
+    rc = load().wt_logprob_gather_batch(logits.data_ptr(), dt, logits.stride(0) if n > 1 else V, n, V, tokens.data_ptr(), sp,
+                                        srows, out.data_ptr(), _stream())
+    _check(rc, "wt_logprob_gather_batch")
+    return out
+
+
+def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000):
+    """pcm: (B, n_samples) fp32; mel_fb: (n_mels, 201) fp32.  Returns (mel (B,n_mels,n_frames), gmax (B,))."""
+    _need_cuda(pcm, "pcm")
+    pcm = pcm.contiguous().float()
+    mel_fb = mel_fb.to(pcm.device).contiguous().float()
+    B, N = pcm.shape
+    M = mel_fb.shape[0]
+    assert mel_fb.shape[1] == 201
+    mel = torch.empty((B, M, n_frames), dtype=torch.float32, device=pcm.device)
+    gmax = torch.empty(B, dtype=torch.float32, device=pcm.device)
+    nv = None if n_valid_samples is None else n_valid_samples.to(device=pcm.device, dtype=torch.int32).contiguous()
+    rc = load().wt_logmel_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
+                                gmax.data_ptr(), _stream())
+    _check(rc, "wt_logmel_batch")
+    return mel, gmax

@@ -1,0 +1,277 @@
+"""Word alignment of Whisper segments on the MI355X: host mirror of the
+reference's ``perform_word_alignment`` seam
+(/root/reference/whisper_timestamped/transcribe.py:1428-1793) on top of the
+HIP kernels in libwtalign.so.
+
+Split of work
+  host (Python, integer/string logic) : frame window, token->word grouping,
+      "too much text" truncation (:1516-1535), jumps -> word times.
+  device (HIP, one batched launch set for any number of units): head select,
+      median filter, softmax, head mean, column norm, padding mask, DTW,
+      backtrack, jumps (:1540-1581, :1648-1652).
+
+``perform_word_alignment`` keeps the reference's signature and return value
+(one unit).  ``AlignmentBatch`` is the MI355X-first entry: queue any number of
+units (segments of many 30 s windows), run them in one go.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .words import (AUDIO_TIME_PER_TOKEN, N_AUDIO_CTX, _punctuation, frame_window, split_tokens_on_spaces,
+                    split_tokens_on_unicode, trailing_punctuation_counts, words_from_jumps)
+
+logger = logging.getLogger("whisper_timestamped")
+
+
+def head_pairs(alignment_heads):
+    """None | sparse COO (L,H) bool tensor (what the reference carries) | (n,2) array -> list of (layer, head) or None."""
+    if alignment_heads is None:
+        return None
+    if isinstance(alignment_heads, torch.Tensor):
+        if alignment_heads.is_sparse:
+            return [(int(l), int(h)) for l, h in alignment_heads.coalesce().indices().T.tolist()]
+        if alignment_heads.dtype == torch.bool:
+            return [(int(l), int(h)) for l, h in alignment_heads.nonzero().tolist()]
+    return [(int(l), int(h)) for l, h in np.asarray(alignment_heads).reshape(-1, 2).tolist()]
+
+
+def max_duration_from_padding(start_of_padding):
+    """transcribe.py:1554-1558: find_start_padding(mfcc) // 2 (None stays None)."""
+    if start_of_padding is None or start_of_padding < 0:
+        return None
+    return int(start_of_padding) // 2
+
+
+@dataclass
+class AlignmentUnit:
+    tokens: list
+    qk: torch.Tensor            # (n_sel, T, n_ctx) logits of the selected heads, on the GPU
+    start_token: int
+    end_token: int
+    pad_from: int               # -1 = no mask
+    words: list
+    word_pieces: list
+    word_ids: list
+    punct_counts: list
+    refine_nframes: int
+    unfinished_decoding: bool
+    detect_disfluencies: bool
+    tokenizer: object
+    tag: object = None          # caller's handle
+
+    @property
+    def T(self):
+        return len(self.tokens)
+
+    @property
+    def F(self):
+        return self.end_token - self.start_token
+
+
+def _gather_heads(attention_weights, pairs, device):
+    """list of L tensors (1,H,T,n_ctx) -> (A,T,n_ctx) on `device` (only the selected heads move)."""
+    if pairs is None:
+        ws = [torch.as_tensor(w).to(device) for w in attention_weights]
+        cat = torch.cat(ws)                                   # (L,H,T,n_ctx), transcribe.py:1512
+        return cat.reshape(-1, *cat.shape[-2:]).contiguous()
+    rows = [torch.as_tensor(attention_weights[l])[0, h].to(device) for l, h in pairs]
+    return torch.stack(rows).contiguous()
+
+
+def prepare_unit(tokens, attention_weights, tokenizer, use_space=True, mfcc=None, refine_whisper_precision_nframes=0,
+                 remove_punctuation_from_words=False, include_punctuation_in_timing=False, unfinished_decoding=False,
+                 alignment_heads=None, detect_disfluencies=True, start_of_padding="auto", device=None, tag=None):
+    """Host part of perform_word_alignment up to the kernel call.  Returns an
+    AlignmentUnit, or None for the empty segment of transcribe.py:1478-1481."""
+    tokens = [int(t) for t in tokens]
+    show = lambda: tokenizer.decode_with_timestamps(tokens)  # noqa: E731
+    win = frame_window(tokens, tokenizer.timestamp_begin, refine_whisper_precision_nframes, show)
+    if win is None:
+        return None
+    start_token, end_token = win
+
+    for w in attention_weights:
+        assert w.shape[-2] == len(tokens), f"Attention weights have wrong shape: {w.shape[-2]} (expected {len(tokens)})."
+    num_frames = end_token - start_token
+    if len(tokens) > num_frames:                               # transcribe.py:1516-1535
+        logger.warning(f"Too much text ({len(tokens)} tokens) for the given number of frames ({num_frames}) in: "
+                       f"{show()}\nThe end of the text will be removed.")
+        keep = num_frames - 1
+        return prepare_unit(
+            tokens[:keep] + [tokens[-1]],
+            [torch.cat([torch.as_tensor(w)[:, :, :keep, :], torch.as_tensor(w)[:, :, -1:, :]], dim=-2)
+             for w in attention_weights],
+            tokenizer, use_space=use_space, mfcc=mfcc,
+            refine_whisper_precision_nframes=refine_whisper_precision_nframes,
+            remove_punctuation_from_words=remove_punctuation_from_words,
+            include_punctuation_in_timing=False,               # the reference's recursion drops this argument
+            unfinished_decoding=True, alignment_heads=alignment_heads, detect_disfluencies=detect_disfluencies,
+            start_of_padding=start_of_padding, device=device, tag=tag)
+
+    splitter = split_tokens_on_spaces if use_space else split_tokens_on_unicode
+    words, word_pieces, word_ids = splitter(tokens, tokenizer, remove_punctuation_from_words=remove_punctuation_from_words)
+    punct_counts = trailing_punctuation_counts(word_pieces, include_punctuation_in_timing)
+
+    if device is None:
+        device = next((w.device for w in attention_weights if isinstance(w, torch.Tensor) and w.is_cuda),
+                      torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+    if device is None:
+        raise _lib.WtError("no GPU: the word-alignment kernels have no CPU fallback")
+    qk = _gather_heads(attention_weights, head_pairs(alignment_heads), device)
+    assert end_token <= qk.shape[-1]
+
+    if start_of_padding == "auto":
+        start_of_padding = None
+        if mfcc is not None:
+            sp = int(_lib.find_start_padding(torch.as_tensor(mfcc).to(device).float().reshape(1, *mfcc.shape[-2:]))[0])
+            start_of_padding = None if sp < 0 else sp
+    max_duration = max_duration_from_padding(start_of_padding)
+    pad_from = -1
+    if max_duration:                                           # transcribe.py:1561-1565
+        if start_token >= max_duration:
+            logger.warning("Got start time outside of audio boundary")
+        else:
+            pad_from = max_duration
+    return AlignmentUnit(tokens, qk, start_token, end_token, pad_from, words, word_pieces, word_ids, punct_counts,
+                         refine_whisper_precision_nframes, unfinished_decoding, detect_disfluencies, tokenizer, tag)
+
+
+class AlignmentBatch:
+    """Queue AlignmentUnits, run cost + DTW for all of them with one launch
+    set, then turn jumps into words on the host."""
+
+    def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False):
+        self.units: list[AlignmentUnit] = []
+        self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
+        self.keep_cost, self.want_path = keep_cost, want_path
+        self.cost = self.jumps = self.descs = None
+        self.path_i = self.path_j = self.path_len = self.dist = None
+
+    def add(self, unit: AlignmentUnit | None):
+        if unit is not None:
+            self.units.append(unit)
+        return unit
+
+    def run(self):
+        units = self.units
+        if not units:
+            return []
+        dev = units[0].qk.device
+        dt = units[0].qk.dtype
+        esz = units[0].qk.element_size()
+        base = min(u.qk.data_ptr() for u in units)
+        descs = _lib.make_descs(len(units))
+        n_sel = units[0].qk.shape[0]
+        for d, u in zip(descs, units):
+            assert u.qk.dtype == dt and u.qk.device == dev and u.qk.shape[0] == n_sel and u.qk.is_contiguous()
+            off = u.qk.data_ptr() - base
+            assert off % esz == 0
+            d["qk_offset"] = off // esz
+            d["head_stride"] = u.qk.stride(0)
+            d["row_stride"] = u.qk.stride(1)
+            d["T"], d["F"] = u.T, u.F
+            d["start_token"], d["pad_from"] = u.start_token, u.pad_from
+        n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
+        descs_dev = _lib.descs_to_device(descs, dev)
+        head_idx = torch.arange(n_sel, dtype=torch.int32, device=dev)
+        cost = torch.empty(n_cost, dtype=torch.float32, device=dev)
+        jumps = torch.empty(n_jumps, dtype=torch.int32, device=dev)
+        if self.want_path:
+            self.path_i = torch.empty(n_path, dtype=torch.int32, device=dev)
+            self.path_j = torch.empty(n_path, dtype=torch.int32, device=dev)
+            self.path_len = torch.empty(len(units), dtype=torch.int32, device=dev)
+            self.dist = torch.empty(len(units), dtype=torch.float64, device=dev)
+        # a fake base tensor is not needed: the ABI takes raw pointers
+        L = _lib.load()
+        rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
+                              len(units), head_idx.data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
+                              cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
+                              _lib._ptr(self.path_len), _lib._ptr(self.dist), _lib._stream())
+        _lib._check(rc, "wt_align_batch")
+        self.descs, self.cost, self.jumps = descs, cost, jumps
+        jumps_host = jumps.cpu().numpy()                       # the one device->host sync of the batch
+        need_cost = self.keep_cost or any(u.detect_disfluencies for u in units)
+        cost_host = cost.cpu().numpy() if need_cost else None
+        out = []
+        for d, u in zip(descs, units):
+            j0 = int(d["jumps_offset"])
+            jm = jumps_host[j0:j0 + u.T + 1].astype(np.int64)
+            cm = None
+            if cost_host is not None:
+                c0 = int(d["cost_offset"])
+                cm = cost_host[c0:c0 + u.T * u.F].reshape(u.T, u.F)
+            out.append(finish_unit(u, jm, cm))
+        return out
+
+    def unit_cost(self, k):
+        d = self.descs[k]
+        c0 = int(d["cost_offset"])
+        return self.cost[c0:c0 + int(d["T"]) * int(d["F"])].reshape(int(d["T"]), int(d["F"]))
+
+    def unit_path(self, k):
+        d = self.descs[k]
+        n = int(self.path_len[k])
+        p0 = int(d["path_offset"])
+        return self.path_i[p0:p0 + n], self.path_j[p0:p0 + n]
+
+
+def detect_disfluences(unit: AlignmentUnit, jumps, cost):
+    """transcribe.py:1654-1683 on the host (scipy.signal.find_peaks on the cost
+    rows the kernel produced) -- SURVEY 'next' row N1, off by default in the API."""
+    from scipy.signal import find_peaks
+    jumps_start = jumps.copy()
+    disfluences = {}
+    for i_token, (tok, begin, end) in enumerate(zip(unit.tokens, jumps[:-1], jumps[1:])):
+        profile = -cost[i_token, begin:end].astype(np.float64)
+        peaks, props = find_peaks(profile, width=3, prominence=0.02)
+        if len(peaks) > 1:
+            left = [round(x) for x in props["left_ips"]] if "left_ips" in props else props["left_bases"]
+            new_begin = left[-1] + begin
+            jumps_start[i_token] = new_begin
+            if new_begin != begin:
+                if unit.tokenizer.decode_with_timestamps([tok]) not in _punctuation:
+                    disfluences[i_token] = (begin, jumps_start[i_token])
+                else:
+                    disfluences[i_token + 1] = (begin, end)
+    return jumps_start, disfluences
+
+
+def finish_unit(unit: AlignmentUnit, jumps, cost=None):
+    jumps_start, disfluences = jumps, None
+    if unit.detect_disfluencies:
+        jumps_start, disfluences = detect_disfluences(unit, jumps, cost)
+    return words_from_jumps(jumps, jumps_start, unit.words, unit.word_pieces, unit.word_ids, unit.punct_counts,
+                            unit.start_token * AUDIO_TIME_PER_TOKEN, unit.refine_nframes, unit.unfinished_decoding,
+                            disfluences)
+
+
+def perform_word_alignment(tokens, attention_weights, tokenizer, use_space=True, mfcc=None,
+                           refine_whisper_precision_nframes=0, remove_punctuation_from_words=False,
+                           include_punctuation_in_timing=False, unfinished_decoding=False, alignment_heads=None,
+                           medfilt_width=9, qk_scale=1.0, detect_disfluencies=True, subwords_can_be_empty=True,
+                           plot=False, debug=False):
+    """Drop-in for the reference function (same arguments, same list of
+    dict(text, start, end, tokens, tokens_indices)); the numerics run on the GPU."""
+    if not subwords_can_be_empty:
+        raise NotImplementedError("subwords_can_be_empty=False (no caller of the reference passes it)")
+    if plot:
+        raise NotImplementedError("plot_word_alignment: debug plotting is out of scope (SURVEY.md section 2, row 17)")
+    unit = prepare_unit(tokens, attention_weights, tokenizer, use_space=use_space, mfcc=mfcc,
+                        refine_whisper_precision_nframes=refine_whisper_precision_nframes,
+                        remove_punctuation_from_words=remove_punctuation_from_words,
+                        include_punctuation_in_timing=include_punctuation_in_timing,
+                        unfinished_decoding=unfinished_decoding, alignment_heads=alignment_heads,
+                        detect_disfluencies=detect_disfluencies)
+    if unit is None:
+        if debug:
+            logger.debug(f"Got empty segment in {tokenizer.decode_with_timestamps(list(tokens))}")
+        return []
+    batch = AlignmentBatch(medfilt_width=medfilt_width, qk_scale=qk_scale)
+    batch.add(unit)
+    return batch.run()[0]
