@@ -33,8 +33,9 @@ extern "C" {
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
 #define WT_E_HIP (-2)         /* a HIP runtime call failed (see wt_last_error)       */
-#define WT_E_UNSUPPORTED (-3) /* shape outside the kernels' range (T>256, F>1792,
-                                 T>F: the caller applies T.py:1516-1535 first)       */
+#define WT_E_UNSUPPORTED (-3) /* shape outside the kernels' range: T > 256, F > 1792,
+                                 or T > 192 together with F > 1760 (LDS budget of the
+                                 DTW).  The reference never exceeds T <= 226, F <= 1500 */
 
 #define WT_DTYPE_F32 0
 #define WT_DTYPE_F16 1

@@ -95,8 +95,9 @@ def test_dtw_bit_exact_ties_and_masks():
 
 def test_dtw_bit_exact_max_sizes():
     rng = np.random.RandomState(2)
-    costs = [(-rng.rand(256, 1792)).astype(np.float32), (-rng.rand(224, 1500)).astype(np.float32),
-             (-rng.rand(256, 256)).astype(np.float32), (-rng.rand(64, 1792)).astype(np.float32)]
+    costs = [(-rng.rand(256, 1500)).astype(np.float32), (-rng.rand(224, 1500)).astype(np.float32),
+             (-rng.rand(256, 256)).astype(np.float32), (-rng.rand(64, 1792)).astype(np.float32),
+             (-rng.rand(192, 1792)).astype(np.float32), (-rng.rand(256, 1760)).astype(np.float32)]
     check_dtw_exact(costs)
 
 
@@ -108,6 +109,11 @@ def test_dtw_rejects_unsupported():
     t = torch.zeros(300 * 100, device=DEV)
     with pytest.raises(L.WtError):
         L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(301, dtype=torch.int32, device=DEV))
+    descs[0]["T"], descs[0]["F"] = 256, 1792      # > 160 KiB of LDS for the direction planes + boundary rows
+    L.layout_outputs(descs)
+    t = torch.zeros(256 * 1792, device=DEV)
+    with pytest.raises(L.WtError):
+        L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(257, dtype=torch.int32, device=DEV))
 
 
 # ---------------------------------------------------------------------------

@@ -46,6 +46,50 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// DPP butterflies inside each row of 16 lanes, then 4 readlanes: no LDS-crossbar (ds_bpermute) traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rows_combine_max(float v) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {  // result is wave-uniform
+    v = fmaxf(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));  // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));  // row_mirror
+    return rows_combine_max(v);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // fixed summation tree, wave-uniform result
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+
+// exp(t) for t <= 0 on v_exp_f32 with a compensated log2(e) product (<= ~1.5 ulp; ocml's expf costs twice the VALU).
+// t may be a large negative sentinel (-1e30) but not -inf.
+__device__ __forceinline__ float exp_nonpos(float t) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f, LN2 = 0.693147182f;
+    const float yh = t * L2E_HI;
+    const float yl = fmaf(t, L2E_LO, fmaf(t, L2E_HI, -yh));
+    const float e = __builtin_amdgcn_exp2f(yh);
+    return fmaf(e, yl * LN2, e);
+}
+
+// s_waitcnt vmcnt(0) only (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
+__device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // lane i receives lane i-1's value; lane 0 keeps `lane0` (DPP wave_shr:1, GFX9)
 __device__ __forceinline__ double wave_shr1(double v, double lane0) {
     union { double d; int i[2]; } s, o, r;

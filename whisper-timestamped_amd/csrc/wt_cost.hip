@@ -11,12 +11,13 @@
 //   :1568       cost[0,0] = cost.min()
 //
 // Kernel 1 (rowmean): ONE WAVE per (unit, token row).  For each selected head
-//   the row (F <= 1792 fp32 logits) is read once from HBM with coalesced
-//   dword loads, staged in LDS, re-read as one contiguous chunk per lane (+4
-//   halo each side, ds_read_b128, chunk stride chosen bank-conflict-free), and
-//   everything else happens in registers: median-of-9 with the 3x3
-//   sorted-column identity on v_min3/v_med3/v_max3 (7 VALU ops per element),
-//   wave-wide max / sum by cross-lane butterflies, exp, accumulate over heads.
+//   the row (F <= 1792 fp32 logits) is copied ONCE from HBM straight into LDS
+//   (global_load_lds, double-buffered: head a+1 streams in while head a is
+//   being consumed), re-read as one contiguous chunk per lane (+4 halo each
+//   side, ds_read_b128), and everything else happens in registers:
+//   median-of-9 with the 3x3 sorted-column identity on v_min3/v_med3/v_max3
+//   (7 VALU ops per element), wave-wide max / sum by DPP butterflies, exp on
+//   v_exp_f32 with a compensated log2(e) product, accumulate over heads.
 //   No workgroup barrier anywhere.  Algorithmic HBM bytes: A*T*F*4 read +
 //   T*F*4 written.
 // Kernel 2 (colnorm): per 64-column tile, column sum of squares over tokens
@@ -35,14 +36,39 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// C = elements per lane (4,12,20,28: C/4 odd => conflict-free ds_read_b128).
+// Asynchronous copy of one head's row (F logits) into dst[4 .. 4+F): fp32 goes
+// HBM -> LDS directly (global_load_lds, no VGPR round trip, completion tracked by
+// vmcnt); fp16 (a build-side storage option) is converted through registers.
+template <int C>
+__device__ __forceinline__ void stage_row(const float *__restrict__ src, float *dst, int F, int nch, int lane) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        if (k < nch) {  // wave-uniform
+            const int f = min(k * 64 + lane, F - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + f),
+                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 64), 4, 0, 0);
+        }
+    }
+}
+template <int C>
+__device__ __forceinline__ void stage_row(const __half *__restrict__ src, float *dst, int F, int nch, int lane) {
+    float v[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) v[k] = (k < nch) ? __half2float(src[min(k * 64 + lane, F - 1)]) : 0.f;
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+        if (k < nch) dst[4 + k * 64 + lane] = v[k];
+}
+
+// C = elements per lane = 4*ceil(F/256); one instantiation serves (C-4)*64 < F <= C*64.
 template <int C, typename QT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                       const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
                                                       float *__restrict__ cost) {
     constexpr int CAP = C * 64;
-    constexpr int FLO = (C == 4) ? 0 : (C - 8) * 64;  // this instantiation serves FLO < F <= CAP
-    __shared__ __attribute__((aligned(16))) float lds[4][CAP + 8];
+    constexpr int FLO = (C - 4) * 64;
+    constexpr int BUF = CAP + 8;
+    __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];  // per wave: double-buffered row
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -50,11 +76,10 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const int F = d.F;
     const int t = blockIdx.x * 4 + wave;
     if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
+    const int nch = (F + 63) >> 6;
 
-    float *xs = lds[wave];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
-
-    // halo duty of lanes 0..7 (source index inside the row)
+    // halo duty of lanes 0..7: scipy 'reflect' source index of positions -4..-1 and F..F+3
     const int hpos = lane < 4 ? -(lane + 1) : F + (lane - 4);
     const int hsrc = reflect_index(hpos, F);
 
@@ -62,23 +87,15 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 #pragma unroll
     for (int q = 0; q < C; ++q) acc[q] = 0.f;
 
+    stage_row<C>(row0 + (int64_t)head_idx[0] * d.head_stride, lds[wave][0], F, nch, lane);
     for (int a = 0; a < n_heads; ++a) {
-        const QT *src = row0 + (int64_t)head_idx[a] * d.head_stride;
-        float v[C];
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const int f = k * 64 + lane;
-            v[k] = (f < F) ? ld_qk(src + f) : 0.f;
+        float *xs = lds[wave][a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+        wait_vmcnt0();                 // head a's row has landed in LDS
+        wave_lds_fence();
+        if (lane < 8) {
+            const float hv = xs[4 + hsrc];
+            xs[4 + hpos] = hv;
         }
-        const float hv = (lane < 8) ? ld_qk(src + hsrc) : 0.f;
-
-        wave_lds_fence();  // previous head's LDS reads are done (WAR)
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const int f = k * 64 + lane;
-            if (f < F) xs[4 + f] = v[k];
-        }
-        if (lane < 8) xs[4 + hpos] = hv;
         wave_lds_fence();
 
         float x[C + 8];
@@ -88,7 +105,12 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
             const float4 r = xp[k];
             x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
         }
-        // sorted triples (lo,mid,hi) of (x[p],x[p+1],x[p+2])
+        // Row a now lives in registers: start streaming head a+1 into the other buffer; it lands while
+        // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
+        // that follows an LDS-DMA, which would serialise the copy with the reads.)
+        if (a + 1 < n_heads)
+            stage_row<C>(row0 + (int64_t)head_idx[a + 1] * d.head_stride, lds[wave][(a + 1) & 1], F, nch, lane);
+        // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
         float lo[C + 6], mi[C + 6], hi[C + 6];
 #pragma unroll
         for (int p = 0; p < C + 6; ++p) {
@@ -97,23 +119,23 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
             hi[p] = max3f(x[p], x[p + 1], x[p + 2]);
         }
         float m[C];
-        float mx = -INFINITY;
+        float mx = -1e30f;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
             const float med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
                                     min3f(hi[q], hi[q + 3], hi[q + 6]));
             const bool ok = (lane * C + q) < F;
-            m[q] = ok ? med * qk_scale : -INFINITY;
+            m[q] = ok ? med * qk_scale : -1e30f;
             mx = fmaxf(mx, m[q]);
         }
-        mx = wave_max(mx);
+        mx = wave_max_dpp(mx);
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
-            m[q] = expf(m[q] - mx);
+            m[q] = exp_nonpos(m[q] - mx);
             s += m[q];
         }
-        s = wave_sum(s);
+        s = wave_sum_dpp(s);
         const float inv = 1.0f / s;
 #pragma unroll
         for (int q = 0; q < C; ++q) acc[q] += m[q] * inv;
@@ -121,11 +143,19 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
     const float nh = (float)n_heads;
+    float *xs = lds[wave][0];
     wave_lds_fence();
     float4 *op = reinterpret_cast<float4 *>(xs + lane * C);
+    if ((n_heads & (n_heads - 1)) == 0) {  // power of two: x * (1/n) == x / n exactly
+        const float rn = 1.0f / nh;
 #pragma unroll
-    for (int k = 0; k < C / 4; ++k)
-        op[k] = make_float4(acc[4 * k] / nh, acc[4 * k + 1] / nh, acc[4 * k + 2] / nh, acc[4 * k + 3] / nh);
+        for (int k = 0; k < C / 4; ++k)
+            op[k] = make_float4(acc[4 * k] * rn, acc[4 * k + 1] * rn, acc[4 * k + 2] * rn, acc[4 * k + 3] * rn);
+    } else {
+#pragma unroll
+        for (int k = 0; k < C / 4; ++k)
+            op[k] = make_float4(acc[4 * k] / nh, acc[4 * k + 1] / nh, acc[4 * k + 2] / nh, acc[4 * k + 3] / nh);
+    }
     wave_lds_fence();
     float *out = cost + d.cost_offset + (int64_t)t * F;
 #pragma unroll
@@ -188,22 +218,24 @@ __global__ void fix00_kernel(float *__restrict__ cost, const wt_seg_desc *__rest
 template <typename QT>
 static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                           const int32_t *head_idx, int n_heads, float qk_scale, float *cost, hipStream_t st) {
-    int maxT[4] = {0, 0, 0, 0};
+    int maxT[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n_seg; ++i) {
-        const int F = segs_host[i].F;
-        const int c = F <= 256 ? 0 : F <= 768 ? 1 : F <= 1280 ? 2 : 3;
+        const int c = (segs_host[i].F + 255) / 256 - 1;  // C = 4*(c+1)
         if (segs_host[i].T > maxT[c]) maxT[c] = segs_host[i].T;
     }
-#define WT_LAUNCH_ROWMEAN(CI, CC)                                                                                   \
+#define WT_LAUNCH_ROWMEAN(CI)                                                                                       \
     if (maxT[CI] > 0) {                                                                                             \
         dim3 grid((maxT[CI] + 3) / 4, n_seg);                                                                       \
-        hipLaunchKernelGGL((rowmean_kernel<CC, QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, n_heads,       \
-                           qk_scale, cost);                                                                         \
+        hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx,      \
+                           n_heads, qk_scale, cost);                                                                \
     }
-    WT_LAUNCH_ROWMEAN(0, 4)
-    WT_LAUNCH_ROWMEAN(1, 12)
-    WT_LAUNCH_ROWMEAN(2, 20)
-    WT_LAUNCH_ROWMEAN(3, 28)
+    WT_LAUNCH_ROWMEAN(0)
+    WT_LAUNCH_ROWMEAN(1)
+    WT_LAUNCH_ROWMEAN(2)
+    WT_LAUNCH_ROWMEAN(3)
+    WT_LAUNCH_ROWMEAN(4)
+    WT_LAUNCH_ROWMEAN(5)
+    WT_LAUNCH_ROWMEAN(6)
 #undef WT_LAUNCH_ROWMEAN
     WT_HIP(hipGetLastError());
     return WT_OK;

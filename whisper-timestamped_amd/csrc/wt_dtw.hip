@@ -7,55 +7,99 @@
 // operation: f64, candidates in the order
 //     p1 = g[i-1,j-1] + c   p2 = g[i,j-1] + c   p3 = g[i-1,j] + c
 // compared as SUMS with strict '<' (first wins), out-of-range candidates never
-// win.  Each cell therefore gets bit-identical g and direction, and the integer
+// win.  The winning VALUE is min(min(p1,p2),p3) whatever the tie order, so the
+// dependent chain per cell is add -> min -> min; the two strict compares that
+// decide the DIRECTION (p2 < p1, p3 < min(p1,p2)) sit off that chain and are
+// shifted into two per-lane bit planes by one add-with-carry each.  g and the
+// directions are therefore bit-identical to dtw-python's, and the integer
 // outputs (jumps, path) are bit-exact for a given cost matrix.
 //
 // Mapping: one workgroup per unit, one LANE PER TOKEN ROW (wave w owns rows
 // 64w..64w+63).  A wave sweeps anti-diagonals: at local step s lane l is at
 // frame j = s - l; g[i-1,*] arrives from lane l-1 through one DPP wave_shr:1
 // (no LDS, no barrier).  Waves are pipelined, not barrier-stepped: the last
-// row of wave w is streamed to LDS (bnd[w][j]) and published every 16 frames
-// through an LDS progress word that wave w+1 polls, so the whole unit costs
-// F + 64*W (+ ~16 per wave hop) dependent steps instead of a barrier per
-// anti-diagonal.  Directions (2 bit) are packed 16 steps per word into LDS
-// (<= 117 KB) and never touch HBM; each lane streams its own cost row with
-// 16-frame register prefetch.  Algorithmic HBM bytes: T*F*4 read + 4*(T+1)
-// written.  The dependency chain (F+T cells) makes one unit latency-bound;
-// throughput comes from the batch.
+// row of wave w is streamed to LDS (bnd[w][j]) and published every 32 frames
+// through an LDS progress word that wave w+1 polls, so a unit costs about
+// F + 64*W + 32*(W-1) dependent steps instead of a barrier per anti-diagonal.
+// Direction bits (2 per cell) live in LDS only (<= 117 KB); each lane streams
+// its own cost row with a 32-frame register prefetch.  Algorithmic HBM bytes:
+// T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its F+T-cell
+// dependency chain; throughput comes from the batch.
 #include "wt_common.h"
 
 namespace wt {
 
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ void load16(const float *__restrict__ row, int j0, int F, bool row_ok, float (&dst)[16]) {
-    if (row_ok && j0 >= 0 && j0 + 16 <= F) {
+constexpr int BLK = 32;  // steps per block = bits per direction word
+
+__device__ __forceinline__ void load_blk(const float *__restrict__ row, int j0, int F, bool row_ok, float (&dst)[BLK]) {
+    if (row_ok && j0 >= 0 && j0 + BLK <= F) {
         const float4u *p = reinterpret_cast<const float4u *>(row + j0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < BLK / 4; ++k) {
             const float4u r = p[k];
             dst[4 * k] = r.x; dst[4 * k + 1] = r.y; dst[4 * k + 2] = r.z; dst[4 * k + 3] = r.w;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < BLK; ++k) {
             const int j = j0 + k;
             dst[k] = (row_ok && j >= 0 && j < F) ? row[j] : 0.f;
         }
     }
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int k) {
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], k);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], k);
-    return u.d;
+__host__ __device__ inline int dtw_pitch(int F) { return ((F + 63 + BLK - 1) / BLK) | 1; }  // words per row per plane
+__host__ __device__ inline int dtw_bnd_pitch(int F) { return F + 64 + BLK; }                // doubles per boundary row
+
+// in-place wave_shr:1 -- lane 0 keeps what `up` already holds (its +inf, or the edge written below)
+__device__ __forceinline__ void shift_in(double &up, double g) {
+    union { double d; int i[2]; } s, o;
+    s.d = g;
+    o.d = up;
+    o.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], 0x138, 0xf, 0xf, false);
+    o.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], 0x138, 0xf, 0xf, false);
+    up = o.d;
+}
+// lane k of `bv` (the boundary value g[64w-1, s0+k] published by the wave above) as a wave-uniform double
+__device__ __forceinline__ double bcast_lane(double bv, int k) {
+    union { double d; int i[2]; } b;
+    b.d = bv;
+    b.i[0] = __builtin_amdgcn_readlane(b.i[0], k);
+    b.i[1] = __builtin_amdgcn_readlane(b.i[1], k);
+    return b.d;
 }
 
-__host__ __device__ inline int dtw_pitch(int F) { return (((F + 63) + 15) >> 4) | 1; }
+// One 32-step block of the anti-diagonal sweep.  EDGE: this wave has a
+// producer wave above it (lane 0 takes g[i-1,*] from lane k of `bv`).
+// u0/u1 alternate as "g[i-1,j]" and "g[i-1,j-1]" so that no register is copied.
+template <bool EDGE, bool PUBLISH, bool DIST>
+__device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1, double bv,
+                                            uint32_t &wa, uint32_t &wb, double *__restrict__ pub, int s0, int sfinal,
+                                            double &gfinal) {
+#pragma unroll
+    for (int k = 0; k < BLK; ++k) {
+        double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
+        const double diag = (k & 1) ? u0 : u1;   // g[i-1, j-1] (written one step ago)
+        if (EDGE) up = wave_shr1(g, bcast_lane(bv, k));  // lane 0 <- edge, lane l <- g of lane l-1
+        else shift_in(up, g);                             // lane 0 keeps its +inf
+        const double c = (double)cur[k];
+        const double p1 = diag + c;
+        const double p2 = g + c;
+        const double p3 = up + c;
+        const double m12 = __builtin_fmin(p1, p2);
+        const double best = __builtin_fmin(m12, p3);
+        wa = wa + wa + (uint32_t)(p2 < p1);   // plane A: "same token, previous frame" beats the diagonal
+        wb = wb + wb + (uint32_t)(p3 < m12);  // plane B: "previous token, same frame" beats both
+        g = best;
+        if (PUBLISH) pub[k] = best;           // lane 63: bnd[w][j]; other lanes: a dump slot
+        if (DIST && s0 + k == sfinal) gfinal = best;
+    }
+}
 
-__global__ void dtw_kernel(const float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
+template <bool DIST>
+__global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
                            int32_t *__restrict__ path_i, int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
                            double *__restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -70,91 +114,87 @@ __global__ void dtw_kernel(const float *__restrict__ cost, const wt_seg_desc *__
     const bool row_ok = i < T;
     const int nsteps = F + 63;
     const int pitch = dtw_pitch(F);
+    const int bpitch = dtw_bnd_pitch(F);
 
-    uint32_t *dirs = reinterpret_cast<uint32_t *>(smem);                         // [nw*64][pitch]
-    double *bnd = reinterpret_cast<double *>(smem + (size_t)nw * 64 * pitch * 4);  // [nw-1][F]
-    int *prog = reinterpret_cast<int *>(bnd + (size_t)(nw - 1) * F);              // [nw-1]
+    uint32_t *planeA = reinterpret_cast<uint32_t *>(smem);  // [nw*64][pitch]
+    uint32_t *planeB = planeA + (size_t)nw * 64 * pitch;    // [nw*64][pitch]
+    double *bnd = reinterpret_cast<double *>(planeB + (size_t)nw * 64 * pitch);  // [nw-1][bpitch], bnd[w][64 + j]
+    double *dump = bnd + (size_t)(nw - 1) * bpitch;         // [BLK]
+    int *prog = reinterpret_cast<int *>(dump + BLK);         // [nw-1]
     if (threadIdx.x < nw) prog[threadIdx.x] = 0;
     __syncthreads();
 
     const float *crow = cost + d.cost_offset + (int64_t)(row_ok ? i : 0) * F;
     const double INF = __builtin_inf();
-    double g = INF;         // g[i, j-1]
-    double diag = INF;      // g[i-1, j-1]
+    double g = INF;                      // g[i, j-1]
+    double u0 = INF;                     // g[i-1, j] / g[i-1, j-1], alternating
+    double u1 = (i == 0) ? 0.0 : INF;    // first diagonal: 0 + lm[0,0] reproduces cm[0,0] = lm[0,0]
     double gfinal = 0.0;
-    float cur[16], nxt[16];
-    load16(crow, -lane, F, row_ok, cur);
+    const int sfinal = F - 1 + lane;
+    uint32_t wa = 0, wb = 0;
+    float bufA[BLK], bufB[BLK];
+    load_blk(crow, -lane, F, row_ok, bufA);
+    // where this lane publishes its g: lane 63 of a producer wave -> bnd[wave][64 + j], j = s - 63
+    const bool producer = wave < nw - 1;
+    double *pub0 = (producer && lane == 63) ? bnd + (size_t)wave * bpitch + 1 : dump;
+    const int pub_inc = (producer && lane == 63) ? BLK : 0;
 
-    for (int s0 = 0; s0 < nsteps; s0 += 16) {
-        load16(crow, s0 + 16 - lane, F, row_ok, nxt);  // prefetch next block (one block ~ 1k cycles ahead)
-
-        double bvals = INF;
+    auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
+        load_blk(crow, s0 + BLK - lane, F, row_ok, nxt);  // prefetch the next block (~2k cycles ahead)
+        double *pub = pub0 + (size_t)(s0 / BLK) * pub_inc;
         if (wave > 0) {
-            const int need = min(s0 + 16, F);
+            const int need = min(s0 + BLK, F);
             while (__hip_atomic_load(&prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                __builtin_amdgcn_s_sleep(2);
-            const int jb = s0 + lane;
-            if (lane < 16 && jb < F) bvals = bnd[(size_t)(wave - 1) * F + jb];
+                __builtin_amdgcn_s_sleep(1);
+            double bv = INF;
+            if (lane < BLK && s0 + lane < F) bv = bnd[(size_t)(wave - 1) * bpitch + 64 + s0 + lane];
+            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, bv, wa, wb, pub, s0, sfinal, gfinal);
+            else sweep_block<true, false, DIST>(cur, g, u0, u1, bv, wa, wb, pub, s0, sfinal, gfinal);
+        } else {
+            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, INF, wa, wb, pub, s0, sfinal, gfinal);
+            else sweep_block<false, false, DIST>(cur, g, u0, u1, INF, wa, wb, pub, s0, sfinal, gfinal);
         }
-
-        uint32_t dw = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = s0 + k - lane;
-            const double edge = (wave > 0) ? readlane_f64(bvals, k) : INF;  // g[64w-1, s0+k] for lane 0
-            const double up = wave_shr1(g, edge);                          // g[i-1, j]
-            const double c = (double)cur[k];
-            const double p1 = diag + c;
-            const double p2 = g + c;
-            const double p3 = up + c;
-            double best = p1;
-            uint32_t dir = 1;
-            if (p2 < best) { best = p2; dir = 2; }
-            if (p3 < best) { best = p3; dir = 3; }
-            if (k == 0 && s0 == 0 && i == 0) best = c;  // cm[0,0] = lm[0,0]
-            diag = up;
-            g = best;
-            dw |= dir << (2 * k);
-            if (j == F - 1) gfinal = best;
-            if (wave < nw - 1 && lane == 63 && j >= 0 && j < F) bnd[(size_t)wave * F + j] = best;
-        }
-        dirs[(size_t)i * pitch + (s0 >> 4)] = dw;
-        if (wave < nw - 1 && lane == 63) {
-            const int done = min(max(s0 + 16 - 63, 0), F);  // frames of row 64w+63 finished so far
+        planeA[(size_t)i * pitch + s0 / BLK] = wa;
+        planeB[(size_t)i * pitch + s0 / BLK] = wb;
+        if (producer && lane == 63) {
+            const int done = min(max(s0 + BLK - 63, 0), F);  // frames of row 64w+63 finished so far
             __hip_atomic_store(&prog[wave], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    };
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * BLK) {
+        block(bufA, bufB, s0);
+        if (s0 + BLK < nsteps) block(bufB, bufA, s0 + BLK);
     }
-    if (dist && i == T - 1) dist[blockIdx.x] = gfinal;
+    if (DIST && i == T - 1) dist[blockIdx.x] = gfinal;
     __syncthreads();
     if (wave != 0) return;
 
     // ---- backtrack (dtw/_backtrack.py) + jumps (transcribe.py:1648-1652) ----
+    // step s of row r sits at bit (31 - (s & 31)) of word s >> 5:  A=1,B=0 -> dir 2; B=1 -> dir 3; else dir 1
     int32_t *jp = jumps + d.jumps_offset;
     int bi = T - 1, bj = F - 1;
     int len = 1;
     if (lane == 0) jp[T] = F - 1;
     while (bi > 0) {
-        const int li = bi & 63;
-        const int s = bj + li;
-        const int p = s & 15;
-        const uint32_t word = dirs[(size_t)bi * pitch + (s >> 4)];
-        // skip the run of "same token, previous frame" (dir 2) steps inside this word
-        const uint32_t x = word ^ 0xAAAAAAAAu;
-        uint32_t y = (x | (x >> 1)) & 0x55555555u;
-        y &= (p == 15) ? 0xFFFFFFFFu : ((1u << (2 * p + 2)) - 1u);
-        if (y == 0) {
+        const int s = bj + (bi & 63);
+        const int p = s & 31;
+        const size_t w = (size_t)bi * pitch + (s >> 5);
+        const uint32_t A = planeA[w], B = planeB[w];
+        // run of dir-2 steps going down from step position p: bits (31-p) upward
+        uint32_t notrun = ~(A & ~B);                    // 1 where dir != 2
+        notrun &= 0xFFFFFFFFu << (31 - p);              // only positions <= p
+        if (notrun == 0) {
             bj -= p + 1;
             len += p + 1;
             continue;
         }
-        const int q = (31 - __builtin_clz(y)) >> 1;
+        const int bit = __builtin_ctz(notrun);          // lowest set bit = highest step position <= p
+        const int q = 31 - bit;
         bj -= p - q;
         len += p - q;
-        const uint32_t dir = (word >> (2 * q)) & 3u;
         if (lane == 0) jp[bi] = bj;
-        if (dir == 1) { --bi; --bj; } else { --bi; }  // dir 3: previous token, same frame
+        if (!((B >> bit) & 1u)) --bj;                   // dir 1: diagonal; dir 3: previous token, same frame
+        --bi;
         ++len;
     }
     len += bj;  // row 0: straight left to (0,0)
@@ -169,19 +209,38 @@ __global__ void dtw_kernel(const float *__restrict__ cost, const wt_seg_desc *__
         while (true) {
             if (lane == 0) { pi[pos] = bi; pj[pos] = bj; }
             if (bi == 0 && bj == 0) break;
-            uint32_t dir = 2;
-            if (bi > 0) {
-                const int s = bj + (bi & 63);
-                dir = (dirs[(size_t)bi * pitch + (s >> 4)] >> (2 * (s & 15))) & 3u;
-            }
-            if (dir == 1) { --bi; --bj; } else if (dir == 2) { --bj; } else { --bi; }
+            if (bi == 0) { --bj; --pos; continue; }
+            const int s = bj + (bi & 63);
+            const size_t w = (size_t)bi * pitch + (s >> 5);
+            const int bit = 31 - (s & 31);
+            const uint32_t a = (planeA[w] >> bit) & 1u, b = (planeB[w] >> bit) & 1u;
+            if (b) { --bi; } else if (a) { --bj; } else { --bi; --bj; }
             --pos;
         }
     }
 }
 
 size_t dtw_lds_bytes(int nw, int F) {
-    return (size_t)nw * 64 * dtw_pitch(F) * 4 + (size_t)(nw - 1) * F * 8 + 16;
+    return (size_t)2 * nw * 64 * dtw_pitch(F) * 4 + ((size_t)(nw - 1) * dtw_bnd_pitch(F) + BLK) * 8 + 16;
+}
+
+template <bool DIST>
+static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
+                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    for (int nw = 1; nw <= 4; ++nw) {
+        if (maxF[nw] == 0) continue;
+        const size_t lds = dtw_lds_bytes(nw, maxF[nw]);
+        hipLaunchKernelGGL(dtw_kernel<DIST>, dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i, path_j,
+                           path_len, dist);
+    }
+    WT_HIP(hipGetLastError());
+    return WT_OK;
 }
 
 int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
@@ -201,20 +260,12 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
         const int nw = (d.T + 63) / 64;
         if (d.F > maxF[nw]) maxF[nw] = d.F;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024));
-        attr_set = true;
+    if (dtw_lds_bytes(4, maxF[4] ? maxF[4] : 1) > 160 * 1024) {
+        set_error("wt_dtw_batch: T>192 with F=%d needs more than 160 KiB of LDS", maxF[4]);
+        return WT_E_UNSUPPORTED;
     }
-    for (int nw = 1; nw <= 4; ++nw) {
-        if (maxF[nw] == 0) continue;
-        const size_t lds = dtw_lds_bytes(nw, maxF[nw]);
-        hipLaunchKernelGGL(dtw_kernel, dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i, path_j, path_len,
-                           dist);
-    }
-    WT_HIP(hipGetLastError());
-    return WT_OK;
+    return dist ? launch_dtw<true>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, st)
+                : launch_dtw<false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, st);
 }
 
 }  // namespace wt

@@ -39,18 +39,25 @@ __device__ __forceinline__ int enc_key(float v) {
 }
 __device__ __forceinline__ float dec_key(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-__global__ void logmel_init_kernel(int *keys, int *bands, const float *__restrict__ fb, int n_chunks, int n_mels) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_chunks) keys[t] = (int)0x80000000;
-    if (t < n_mels) {  // non-zero band [lo,hi) of mel filter t
-        int lo = 201, hi = 0;
-        for (int k = 0; k < 201; ++k)
-            if (fb[t * 201 + k] != 0.f) {
-                if (k < lo) lo = k;
-                hi = k + 1;
-            }
-        bands[2 * t] = lo < hi ? lo : 0;
-        bands[2 * t + 1] = lo < hi ? hi : 0;
+// block m < n_mels: non-zero band [lo,hi) of mel filter m; block n_mels: reset the per-chunk max keys
+__global__ __launch_bounds__(256) void logmel_init_kernel(int *keys, int *bands, const float *__restrict__ fb, int n_chunks,
+                                                          int n_mels) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    if (m == n_mels) {
+        for (int t = tid; t < n_chunks; t += 256) keys[t] = (int)0x80000000;
+        return;
+    }
+    __shared__ int s_lo, s_hi;
+    if (tid == 0) { s_lo = 201; s_hi = 0; }
+    __syncthreads();
+    if (tid < 201 && fb[m * 201 + tid] != 0.f) {
+        atomicMin(&s_lo, tid);
+        atomicMax(&s_hi, tid + 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bands[2 * m] = s_lo < s_hi ? s_lo : 0;
+        bands[2 * m + 1] = s_lo < s_hi ? s_hi : 0;
     }
 }
 
@@ -225,8 +232,7 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     rc = scratch2(((size_t)n_chunks + 2 * (size_t)n_mels) * sizeof(int), (void **)&ws);
     if (rc) return rc;
     int *keys = ws, *bands = ws + n_chunks;
-    const int ninit = n_chunks > n_mels ? n_chunks : n_mels;
-    hipLaunchKernelGGL(logmel_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, st, keys, bands, mel_fb, n_chunks, n_mels);
+    hipLaunchKernelGGL(logmel_init_kernel, dim3(n_mels + 1), dim3(256), 0, st, keys, bands, mel_fb, n_chunks, n_mels);
     hipLaunchKernelGGL(stft_mel_kernel, dim3((n_frames + FPB - 1) / FPB, n_chunks), dim3(256), 0, st, pcm, n_samples,
                        n_valid_samples, mel_fb, bands, n_mels, n_frames, mel_out, keys);
     const int total = n_mels * n_frames;

@@ -151,32 +151,51 @@ int logprob_gather_batch(const void *logits, int dtype, int64_t row_stride, int 
 }
 
 // ---------------------------------------------------------------------------
-// transcribe.py:1795-1805.  One workgroup per (n_mels, n_cols) window; thread
-// c-strided over columns so every mel row is read coalesced.
+// transcribe.py:1795-1805.  One workgroup per (n_mels, n_cols) window.  Like
+// the reference it looks at the last column first (80 floats: the common "no
+// padding" answer costs one tiny read) and only then walks BACKWARDS, 256
+// columns per trip with every mel row read coalesced, stopping at the first
+// tile that holds a non-zero column -- the bytes touched are proportional to
+// the length of the padding, not to the window.
 __global__ __launch_bounds__(256) void find_start_padding_kernel(const float *__restrict__ mel, int n_mels, int n_cols,
                                                                  int32_t *__restrict__ out) {
     const float *m = mel + (int64_t)blockIdx.x * n_mels * n_cols;
     const int tid = threadIdx.x;
-    int last_nz = 0;  // highest column in [1, n_cols-2] holding a value != 0
-    int tail_nz = 0;  // last column not all-zero?
-    for (int c = tid; c < n_cols; c += 256) {
-        bool nz = false;
-        for (int r = 0; r < n_mels; ++r) nz |= !(m[(int64_t)r * n_cols + c] == 0.f);
-        if (nz) {
-            if (c == n_cols - 1) tail_nz = 1;
-            else if (c >= 1) last_nz = c;  // c ascending per thread
+    __shared__ int s_red[4];
+    __shared__ int s_flag;
+    // 1. last column all exactly zero?  (min == max == 0 in the reference; -0.0 == 0, NaN != 0)
+    int nz = 0;
+    for (int r = tid; r < n_mels; r += 256) nz |= !(m[(int64_t)r * n_cols + n_cols - 1] == 0.f);
+    nz = wave_max_i(nz);
+    if ((tid & 63) == 0) s_red[tid >> 6] = nz;
+    __syncthreads();
+    if (tid == 0) s_flag = s_red[0] | s_red[1] | s_red[2] | s_red[3];
+    __syncthreads();
+    if (s_flag) {
+        if (tid == 0) out[blockIdx.x] = -1;
+        return;
+    }
+    // 2. highest column in [1, n_cols-2] that differs from zero
+    for (int hi = n_cols - 2; hi >= 1; hi -= 256) {
+        const int c = hi - tid;
+        int found = 0;
+        if (c >= 1) {
+            bool any = false;
+#pragma unroll 8
+            for (int r = 0; r < n_mels; ++r) any |= !(m[(int64_t)r * n_cols + c] == 0.f);
+            found = any ? c : 0;
+        }
+        found = wave_max_i(found);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = found;
+        __syncthreads();
+        const int best = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+        if (best > 0) {
+            if (tid == 0) out[blockIdx.x] = best + 1;
+            return;
         }
     }
-    last_nz = wave_max_i(last_nz);
-    tail_nz = wave_max_i(tail_nz);
-    __shared__ int s_last[4], s_tail[4];
-    if ((tid & 63) == 0) { s_last[tid >> 6] = last_nz; s_tail[tid >> 6] = tail_nz; }
-    __syncthreads();
-    if (tid == 0) {
-        const int l = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-        const int t = max(max(s_tail[0], s_tail[1]), max(s_tail[2], s_tail[3]));
-        out[blockIdx.x] = t ? -1 : (l > 0 ? l + 1 : 0);
-    }
+    if (tid == 0) out[blockIdx.x] = 0;
 }
 
 int find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, hipStream_t st) {
