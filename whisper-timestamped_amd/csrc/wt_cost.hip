@@ -165,35 +165,52 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     }
 }
 
-__global__ __launch_bounds__(256) void colnorm_kernel(float *__restrict__ cost, const wt_seg_desc *__restrict__ segs,
-                                                      unsigned *__restrict__ segmax) {
+// 64 columns x all T token rows per workgroup of 16 waves: wave w owns rows w, w+16, ... (<= 16 rows for
+// T <= 256), all loaded before the first use so that one round trip to L2/HBM covers the whole column.
+constexpr int CN_WAVES = 16;
+constexpr int CN_ROWS = (WT_MAX_TOKENS + CN_WAVES - 1) / CN_WAVES;
+__global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restrict__ cost,
+                                                                const wt_seg_desc *__restrict__ segs,
+                                                                unsigned *__restrict__ segmax) {
     const wt_seg_desc d = segs[blockIdx.y];
     const int F = d.F, T = d.T;
     if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
-    __shared__ double ssq[4][64];
-    __shared__ float smx[4][64];
+    __shared__ double ssq[CN_WAVES][64];
+    __shared__ float smx[CN_WAVES][64];
     __shared__ float snorm[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = blockIdx.x * 64 + lane;
     const bool valid = f < F;
     const bool masked_col = d.pad_from >= 0 && f >= d.pad_from;
-    float *base = cost + d.cost_offset;
+    float *base = cost + d.cost_offset + (valid ? f : 0);
 
+    float v[CN_ROWS];
+#pragma unroll
+    for (int r = 0; r < CN_ROWS; ++r) {
+        const int t = wave + r * CN_WAVES;
+        v[r] = (valid && t < T) ? base[(int64_t)t * F] : 0.f;
+    }
     double ss = 0.0;
     float mx = 0.f;
-    for (int t = wave; t < T; t += 4) {
-        const float v = valid ? base[(int64_t)t * F + f] : 0.f;
-        ss += (double)v * (double)v;
-        if (!masked_col || t == T - 1) mx = fmaxf(mx, v);
+#pragma unroll
+    for (int r = 0; r < CN_ROWS; ++r) {
+        const int t = wave + r * CN_WAVES;
+        ss += (double)v[r] * (double)v[r];
+        if (!masked_col || t == T - 1) mx = fmaxf(mx, v[r]);
     }
     ssq[wave][lane] = ss;
     smx[wave][lane] = mx;
     __syncthreads();
     if (wave == 0) {
-        const double tot = (ssq[0][lane] + ssq[1][lane]) + (ssq[2][lane] + ssq[3][lane]);
+        double tot = 0.0;
+        float m = 0.f;
+#pragma unroll
+        for (int w = 0; w < CN_WAVES; ++w) {
+            tot += ssq[w][lane];
+            m = fmaxf(m, smx[w][lane]);
+        }
         const float norm = sqrtf((float)tot);
         snorm[lane] = norm;
-        float m = fmaxf(fmaxf(smx[0][lane], smx[1][lane]), fmaxf(smx[2][lane], smx[3][lane]));
         float r = valid ? m / norm : 0.f;  // max_t(w/norm) == max_t(w)/norm: IEEE division is monotone
         r = wave_max(r);
         if (lane == 0) atomicMax(segmax + blockIdx.y, __float_as_uint(r));
@@ -201,10 +218,10 @@ __global__ __launch_bounds__(256) void colnorm_kernel(float *__restrict__ cost, 
     __syncthreads();
     const float norm = snorm[lane];
     if (valid) {
-        for (int t = wave; t < T; t += 4) {
-            float *p = base + (int64_t)t * F + f;
-            const float v = *p;
-            *p = (masked_col && t < T - 1) ? 0.f : -(v / norm);
+#pragma unroll
+        for (int r = 0; r < CN_ROWS; ++r) {
+            const int t = wave + r * CN_WAVES;
+            if (t < T) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
         }
     }
 }
@@ -274,7 +291,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
         return WT_E_BADARG;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(256), 0, st, cost, segs_dev, segmax);
+    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segmax);
     hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segmax, n_seg);
     WT_HIP(hipGetLastError());
     return WT_OK;

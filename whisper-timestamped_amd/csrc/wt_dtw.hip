@@ -76,8 +76,8 @@ __device__ __forceinline__ double bcast_lane(double bv, int k) {
 // u0/u1 alternate as "g[i-1,j]" and "g[i-1,j-1]" so that no register is copied.
 template <bool EDGE, bool PUBLISH, bool DIST>
 __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1, double bv,
-                                            uint32_t &wa, uint32_t &wb, double *__restrict__ pub, int s0, int sfinal,
-                                            double &gfinal) {
+                                            uint32_t &wa, uint32_t &wb, double *__restrict__ pub, bool is_pub, int s0,
+                                            int sfinal, double &gfinal) {
 #pragma unroll
     for (int k = 0; k < BLK; ++k) {
         double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
@@ -93,7 +93,8 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
         wa = wa + wa + (uint32_t)(p2 < p1);   // plane A: "same token, previous frame" beats the diagonal
         wb = wb + wb + (uint32_t)(p3 < m12);  // plane B: "previous token, same frame" beats both
         g = best;
-        if (PUBLISH) pub[k] = best;           // lane 63: bnd[w][j]; other lanes: a dump slot
+        if (PUBLISH && is_pub) pub[k] = best;  // lane 63 only: bnd[w][64 + j] (a same-address store from all
+                                               // 64 lanes would serialise in the LDS: measured 3x slower)
         if (DIST && s0 + k == sfinal) gfinal = best;
     }
 }
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     load_blk(crow, -lane, F, row_ok, bufA);
     // where this lane publishes its g: lane 63 of a producer wave -> bnd[wave][64 + j], j = s - 63
     const bool producer = wave < nw - 1;
-    double *pub0 = (producer && lane == 63) ? bnd + (size_t)wave * bpitch + 1 : dump;
-    const int pub_inc = (producer && lane == 63) ? BLK : 0;
+    const bool is_pub = producer && lane == 63;
+    double *pub0 = is_pub ? bnd + (size_t)wave * bpitch + 1 : dump;
+    const int pub_inc = is_pub ? BLK : 0;
 
     auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
         load_blk(crow, s0 + BLK - lane, F, row_ok, nxt);  // prefetch the next block (~2k cycles ahead)
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
                 __builtin_amdgcn_s_sleep(1);
             double bv = INF;
             if (lane < BLK && s0 + lane < F) bv = bnd[(size_t)(wave - 1) * bpitch + 64 + s0 + lane];
-            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, bv, wa, wb, pub, s0, sfinal, gfinal);
-            else sweep_block<true, false, DIST>(cur, g, u0, u1, bv, wa, wb, pub, s0, sfinal, gfinal);
+            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, bv, wa, wb, pub, is_pub, s0, sfinal, gfinal);
+            else sweep_block<true, false, DIST>(cur, g, u0, u1, bv, wa, wb, pub, is_pub, s0, sfinal, gfinal);
         } else {
-            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, INF, wa, wb, pub, s0, sfinal, gfinal);
-            else sweep_block<false, false, DIST>(cur, g, u0, u1, INF, wa, wb, pub, s0, sfinal, gfinal);
+            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, INF, wa, wb, pub, is_pub, s0, sfinal, gfinal);
+            else sweep_block<false, false, DIST>(cur, g, u0, u1, INF, wa, wb, pub, is_pub, s0, sfinal, gfinal);
         }
         planeA[(size_t)i * pitch + s0 / BLK] = wa;
         planeB[(size_t)i * pitch + s0 / BLK] = wb;

@@ -39,36 +39,60 @@ __device__ __forceinline__ int enc_key(float v) {
 }
 __device__ __forceinline__ float dec_key(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
 
-// block m < n_mels: non-zero band [lo,hi) of mel filter m; block n_mels: reset the per-chunk max keys
-__global__ __launch_bounds__(256) void logmel_init_kernel(int *keys, int *bands, const float *__restrict__ fb, int n_chunks,
-                                                          int n_mels) {
-    const int m = blockIdx.x, tid = threadIdx.x;
-    if (m == n_mels) {
-        for (int t = tid; t < n_chunks; t += 256) keys[t] = (int)0x80000000;
-        return;
-    }
-    __shared__ int s_lo, s_hi;
-    if (tid == 0) { s_lo = 201; s_hi = 0; }
+constexpr int NNZ_CAP = 768;        // compact (banded) filterbank weights kept in LDS
+constexpr int MAX_MELS = 256;
+
+// Per-call preparation, ONE workgroup: reset the per-chunk max keys and turn the dense (n_mels x 201)
+// filterbank into its banded form: lo[m], n[m], off[m] and the concatenated non-zero spans.
+// ws layout (ints): keys[n_chunks] | lo[MAX_MELS] | n[MAX_MELS] | off[MAX_MELS] | total | weights[NNZ_CAP]
+__global__ __launch_bounds__(256) void logmel_init_kernel(int *ws, const float *__restrict__ fb, int n_chunks, int n_mels) {
+    __shared__ int s_lo[MAX_MELS], s_hi[MAX_MELS], s_off[MAX_MELS];
+    const int tid = threadIdx.x;
+    int *keys = ws, *lo = ws + n_chunks, *cnt = lo + MAX_MELS, *off = cnt + MAX_MELS, *total = off + MAX_MELS;
+    float *wts = reinterpret_cast<float *>(total + 1);
+    for (int t = tid; t < n_chunks; t += 256) keys[t] = (int)0x80000000;
+    s_lo[tid] = 201;
+    s_hi[tid] = 0;
     __syncthreads();
-    if (tid < 201 && fb[m * 201 + tid] != 0.f) {
-        atomicMin(&s_lo, tid);
-        atomicMax(&s_hi, tid + 1);
+    for (int e = tid; e < n_mels * 201; e += 256) {
+        if (fb[e] != 0.f) {
+            const int m = e / 201, k = e - m * 201;
+            atomicMin(&s_lo[m], k);
+            atomicMax(&s_hi[m], k + 1);
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        bands[2 * m] = s_lo < s_hi ? s_lo : 0;
-        bands[2 * m + 1] = s_lo < s_hi ? s_hi : 0;
+    const int width = (tid < n_mels && s_lo[tid] < s_hi[tid]) ? s_hi[tid] - s_lo[tid] : 0;
+    if (width == 0) s_lo[tid] = 0;
+    s_off[tid] = width;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
+        const int v = tid >= o ? s_off[tid - o] : 0;
+        __syncthreads();
+        s_off[tid] += v;
+        __syncthreads();
     }
+    const int my_off = s_off[tid] - width;
+    if (tid < n_mels) { lo[tid] = s_lo[tid]; cnt[tid] = width; off[tid] = my_off; }
+    const int tot = s_off[255];
+    if (tid == 0) *total = tot;
+    if (tot <= NNZ_CAP)
+        for (int m = 0; m < n_mels; ++m) {  // block-cooperative copy of each band
+            const int w = s_off[m] - (m ? s_off[m - 1] : 0), o = s_off[m] - w;
+            for (int k = tid; k < w; k += 256) wts[o + k] = fb[m * 201 + s_lo[m] + k];
+        }
 }
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__ pcm, int64_t n_samples,
                                                        const int32_t *__restrict__ n_valid_samples,
-                                                       const float *__restrict__ fb, const int *__restrict__ bands, int n_mels,
-                                                       int n_frames, float *__restrict__ mel_out, int *__restrict__ keys) {
+                                                       const float *__restrict__ fb, const int *__restrict__ ws, int n_chunks,
+                                                       int n_mels, int n_frames, float *__restrict__ mel_out) {
     __shared__ float span[SPAN];
     __shared__ float2 w400[400];
-    __shared__ float2 yp[FPB][20][YP];
+    __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
     __shared__ float pw[FPB][204];
+    __shared__ float fbw[NNZ_CAP];
+    __shared__ int fb_lo[MAX_MELS], fb_n[MAX_MELS], fb_off[MAX_MELS];
     __shared__ int smax[4];
 
     const int chunk = blockIdx.y;
@@ -78,7 +102,20 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (f0 >= nvf) return;                    // whole tile is padding (block-uniform)
     const float *x = pcm + (int64_t)chunk * n_samples;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / 20;       // frame slot inside the wave (0..2), lanes 60..63 idle
+    const int u = lane - sub * 20;   // n2 in stage 1, k1 in stage 2
+    const int slot = wave * 3 + sub;
+    const bool act = lane < 60 && (f0 + slot) < nvf;
 
+    // ---- phase A: every global read of the tile is issued here, one latency for all of them ----
+    const int *g_lo = ws + n_chunks, *g_n = g_lo + MAX_MELS, *g_off = g_n + MAX_MELS, *g_tot = g_off + MAX_MELS;
+    const float *g_w = reinterpret_cast<const float *>(g_tot + 1);
+    const int nnz = *g_tot;
+    const bool banded = nnz <= NNZ_CAP;
+    float hw[20];                    // this lane's 20 window taps hann[20*n1 + u]
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) hw[n1] = k_hann[20 * n1 + (lane < 60 ? u : 0)];
     for (int p = tid; p < SPAN; p += 256) {
         int i = f0 * 160 + p - 200;  // centre=True: frame f covers padded[160f, 160f+400)
         if (i < 0) i = -i;           // reflect (no edge repeat)
@@ -87,21 +124,17 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         span[p] = x[i];
     }
     for (int p = tid; p < 400; p += 256) w400[p] = k_w400[p];
+    if (tid < n_mels) { fb_lo[tid] = g_lo[tid]; fb_n[tid] = g_n[tid]; fb_off[tid] = g_off[tid]; }
+    if (banded)
+        for (int p = tid; p < nnz; p += 256) fbw[p] = g_w[p];
     __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int sub = lane / 20;       // frame slot inside the wave (0..2), lanes 60..63 idle
-    const int u = lane - sub * 20;   // n2 in stage 1, k1 in stage 2
-    const int slot = wave * 3 + sub;
-    const bool act = lane < 60 && (f0 + slot) < nvf;
 
     if (act) {
         // ---- stage 1: radix-20 over n1 for this lane's n2 = u ----
         float a[20];
         const float *fr = span + slot * 160;
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * k_hann[20 * n1 + u];
-        float yr[11], yi[11];
+        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hw[n1];
 #pragma unroll
         for (int k1 = 0; k1 <= 10; ++k1) {
             float sr = 0.f, si = 0.f;
@@ -110,26 +143,22 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                 sr = fmaf(a[n1], k_c20[(n1 * k1) % 20], sr);
                 si = fmaf(a[n1], k_s20[(n1 * k1) % 20], si);
             }
-            yr[k1] = sr;
-            yi[k1] = -si;
-        }
-#pragma unroll
-        for (int k1 = 0; k1 < 20; ++k1) {
-            const float re = yr[k1 <= 10 ? k1 : 20 - k1];
-            const float im = k1 <= 10 ? yi[k1] : -yi[20 - k1];
-            const float2 w = w400[u * k1];  // e^{-i t} = (cos t, -sin t)
-            yp[slot][k1][u] = make_float2(re * w.x + im * w.y, im * w.x - re * w.y);
+            yp[slot][k1][u] = make_float2(sr, -si);
         }
     }
     __syncthreads();
     if (act) {
-        // ---- stage 2: radix-20 over n2 for this lane's k1 = u ----
+        // ---- stage 2: twiddle by W400^(n2*k1), radix-20 over n2 for this lane's k1 = u ----
+        const int ks = u <= 10 ? u : 20 - u;
+        const float cj = u <= 10 ? 1.f : -1.f;
         float br[20], bi[20];
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) {
-            const float2 v = yp[slot][u][n2];
-            br[n2] = v.x;
-            bi[n2] = v.y;
+            const float2 v = yp[slot][ks][n2];
+            const float2 w = w400[n2 * u];  // e^{-i t} = (cos t, -sin t)
+            const float re = v.x, im = cj * v.y;
+            br[n2] = re * w.x + im * w.y;
+            bi[n2] = im * w.x - re * w.y;
         }
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
@@ -161,10 +190,15 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     for (int o = tid; o < n_mels * FPB; o += 256) {
         const int m = o / FPB, s = o - m * FPB;
         if (f0 + s >= nvf) continue;
-        const int lo = bands[2 * m], hi = bands[2 * m + 1];
-        const float *w = fb + m * 201;
+        const int lo = fb_lo[m], n = fb_n[m];
         float acc = 0.f;
-        for (int k = lo; k < hi; ++k) acc = fmaf(w[k], pw[s][k], acc);
+        if (banded) {
+            const float *w = fbw + fb_off[m];
+            for (int k = 0; k < n; ++k) acc = fmaf(w[k], pw[s][lo + k], acc);
+        } else {
+            const float *w = fb + m * 201 + lo;
+            for (int k = 0; k < n; ++k) acc = fmaf(w[k], pw[s][lo + k], acc);
+        }
         const float v = log10f(fmaxf(acc, 1e-10f));
         mel_out[((int64_t)chunk * n_mels + m) * n_frames + f0 + s] = v;
         lmax = fmaxf(lmax, v);
@@ -172,7 +206,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     lmax = wave_max(lmax);
     if (lane == 0) smax[wave] = enc_key(lmax);
     __syncthreads();
-    if (tid == 0) atomicMax(keys + chunk, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    if (tid == 0) atomicMax(const_cast<int *>(ws) + chunk, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
 }
 
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const int *__restrict__ keys,
@@ -221,7 +255,7 @@ static int upload_tables(hipStream_t st) {
 
 int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
                  int n_mels, int n_frames, float *mel_out, float *gmax, hipStream_t st) {
-    if (!pcm || !mel_fb || !mel_out || n_chunks < 0 || n_samples < 201 || n_mels <= 0 || n_mels > 256 || n_frames <= 0) {
+    if (!pcm || !mel_fb || !mel_out || n_chunks < 0 || n_samples < 201 || n_mels <= 0 || n_mels > MAX_MELS || n_frames <= 0) {
         set_error("wt_logmel_batch: bad argument");
         return WT_E_BADARG;
     }
@@ -229,12 +263,12 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     int rc = upload_tables(st);
     if (rc) return rc;
     int *ws = nullptr;
-    rc = scratch2(((size_t)n_chunks + 2 * (size_t)n_mels) * sizeof(int), (void **)&ws);
+    rc = scratch2(((size_t)n_chunks + 3 * MAX_MELS + 1 + NNZ_CAP) * sizeof(int), (void **)&ws);
     if (rc) return rc;
-    int *keys = ws, *bands = ws + n_chunks;
-    hipLaunchKernelGGL(logmel_init_kernel, dim3(n_mels + 1), dim3(256), 0, st, keys, bands, mel_fb, n_chunks, n_mels);
+    int *keys = ws;
+    hipLaunchKernelGGL(logmel_init_kernel, dim3(1), dim3(256), 0, st, ws, mel_fb, n_chunks, n_mels);
     hipLaunchKernelGGL(stft_mel_kernel, dim3((n_frames + FPB - 1) / FPB, n_chunks), dim3(256), 0, st, pcm, n_samples,
-                       n_valid_samples, mel_fb, bands, n_mels, n_frames, mel_out, keys);
+                       n_valid_samples, mel_fb, ws, n_chunks, n_mels, n_frames, mel_out);
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, keys, n_valid_samples, n_samples,
