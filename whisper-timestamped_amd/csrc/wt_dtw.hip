@@ -77,13 +77,16 @@ __device__ __forceinline__ void shift_in(double &up, double g) {
     up = o.d;
 }
 
-// lane k of `bv` (the boundary value g[64w-1, s0+k] published by the wave above) as a wave-uniform double
-__device__ __forceinline__ double bcast_lane(double bv, int k) {
+// Boundary feed of a consumer wave: lane k of `bv` holds g[64w-1, s0+k] (published by the wave above).  Each step
+// the register is rotated down by one lane (DPP wave_shl:1), so lane 0 always holds the value of the current
+// step and the wave_shr:1 that delivers g[i-1,*] takes it as its "old" operand -- no v_readlane -> SGPR -> VGPR
+// round trip (measured +50 cycles per step), and the rotation sits off the dependent chain.
+__device__ __forceinline__ void rotate_down(double &bv) {
     union { double d; int i[2]; } b;
     b.d = bv;
-    b.i[0] = __builtin_amdgcn_readlane(b.i[0], k);
-    b.i[1] = __builtin_amdgcn_readlane(b.i[1], k);
-    return b.d;
+    b.i[0] = __builtin_amdgcn_update_dpp(b.i[0], b.i[0], 0x130, 0xf, 0xf, false);  // wave_shl:1, lane 63 keeps its own
+    b.i[1] = __builtin_amdgcn_update_dpp(b.i[1], b.i[1], 0x130, 0xf, 0xf, false);
+    bv = b.d;
 }
 
 // w = 2w + (a < b): one compare into VCC and one add-with-carry (hipcc emits cndmask + shift + or instead)
@@ -116,8 +119,12 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
     for (int k = 0; k < BLK; ++k) {
         double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
         const double diag = (k & 1) ? u0 : u1;   // g[i-1, j-1] (written one step ago)
-        if (EDGE) up = wave_shr1(g, bcast_lane(bv, k));  // lane 0 <- edge, lane l <- g of lane l-1
-        else shift_in(up, g);                             // lane 0 keeps its +inf
+        if (EDGE) {
+            up = wave_shr1(g, bv);  // lane 0 <- edge value of this step (lane 0 of bv), lane l <- g of lane l-1
+            rotate_down(bv);
+        } else {
+            shift_in(up, g);        // lane 0 keeps its +inf
+        }
         const double c = (double)cur[k];
         const double p1 = diag + c;
         const double p2 = g + c;
@@ -150,9 +157,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     const int pitch = dtw_pitch(F);
     const int bpitch = dtw_bnd_pitch(F);
 
-    uint32_t *planeA = reinterpret_cast<uint32_t *>(smem);  // [nw*64][pitch]
-    uint32_t *planeB = planeA + (size_t)nw * 64 * pitch;    // [nw*64][pitch]
-    double *bnd = reinterpret_cast<double *>(planeB + (size_t)nw * 64 * pitch);  // [nw-1][bpitch], bnd[w][64 + j]
+    uint2 *plane = reinterpret_cast<uint2 *>(smem);          // [nw*64][pitch] (.x = plane A word, .y = plane B word)
+    double *bnd = reinterpret_cast<double *>(plane + (size_t)nw * 64 * pitch);  // [nw-1][bpitch], bnd[w][64 + j]
     double *dump = bnd + (size_t)(nw - 1) * bpitch;         // [BLK]
     int *prog = reinterpret_cast<int *>(dump + BLK);         // [nw-1]
     if (threadIdx.x < nw) prog[threadIdx.x] = 0;
@@ -192,8 +198,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
             if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, INF, wa, wb, pubacc, s0, sfinal, gfinal);
             else sweep_block<false, false, DIST>(cur, g, u0, u1, INF, wa, wb, pubacc, s0, sfinal, gfinal);
         }
-        planeA[(size_t)i * pitch + s0 / BLK] = wa;
-        planeB[(size_t)i * pitch + s0 / BLK] = wb;
+        plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
         if (producer && lane < BLK) pubrow[s0 + BLK - 1 - lane] = pubacc;  // lane l holds step s0 + 31 - l
         if (producer && lane == 0) {
             const int done = min(max(s0 + BLK - 63, 0), F);  // frames of row 64w+63 finished so far
@@ -219,8 +224,9 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     while (bi > 0) {
         const int s = bj + (bi & 63);
         const int p = s & 31;
-        const size_t w = (size_t)bi * pitch + (s >> 5);
-        const uint32_t A = planeA[w], B = planeB[w];
+        const uint2 AB = plane[(size_t)bi * pitch + (s >> 5)];
+        // wave-uniform walk: move it to the scalar unit (SALU ops issue in 1 cycle, no VALU dependent-issue latency)
+        const uint32_t A = __builtin_amdgcn_readfirstlane(AB.x), B = __builtin_amdgcn_readfirstlane(AB.y);
         // run of dir-2 steps going down from step position p: bits (31-p) upward
         uint32_t notrun = ~(A & ~B);                    // 1 where dir != 2
         notrun &= 0xFFFFFFFFu << (31 - p);              // only positions <= p
@@ -253,9 +259,10 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
             if (bi == 0 && bj == 0) break;
             if (bi == 0) { --bj; --pos; continue; }
             const int s = bj + (bi & 63);
-            const size_t w = (size_t)bi * pitch + (s >> 5);
+            const uint2 AB = plane[(size_t)bi * pitch + (s >> 5)];
             const int bit = 31 - (s & 31);
-            const uint32_t a = (planeA[w] >> bit) & 1u, b = (planeB[w] >> bit) & 1u;
+            const uint32_t a = (__builtin_amdgcn_readfirstlane(AB.x) >> bit) & 1u;
+            const uint32_t b = (__builtin_amdgcn_readfirstlane(AB.y) >> bit) & 1u;
             if (b) { --bi; } else if (a) { --bj; } else { --bi; --bj; }
             --pos;
         }
