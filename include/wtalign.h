@@ -70,6 +70,17 @@ int wt_version(void);
 const char *wt_last_error(void);
 int wt_shutdown(void);
 
+/* T.py:783-793 hook_attention_weights.  Copies the LAST query row of n_sel heads of one decoder layer's
+ * cross-attention QK logits into the device capture ring (instead of the reference's `w[:, :, -1:, :].cpu()`
+ * of all heads, once per token per layer).
+ *   qk       : device, contiguous [n_heads][n_q][n_ctx] (the layer's (1,H,n_q,1500) tensor), qk_dtype
+ *   heads    : device int32[n_sel], head index inside this layer
+ *   slots    : device int32[n_sel], destination head slot in the ring
+ *   ring     : device, [n_slots][ring_rows][n_ctx] of ring_dtype; writes ring[slots[i]][row][:]        */
+int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ctx, const int32_t *heads,
+                    const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row,
+                    void *stream);
+
 /* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
  * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,
  * softmax over the F-frame window, mean over heads, divide by the per-frame L2

@@ -1,0 +1,63 @@
+"""TEST-ONLY stand-in for the HIP kernels, built from the CPU oracle.
+
+The product has no CPU path (whisper_timestamped._lib refuses CPU tensors).  To
+test the HOST logic (hook state machine, strategy drivers, confidence glue,
+post-processors) in the GPU-less build container, ``install(monkeypatch)``
+replaces the five kernel entry points the host layer calls by oracle-backed
+CPU functions.  Nothing outside tests/ may import this module.
+"""
+import numpy as np
+import torch
+
+from oracle import align_ref as O
+
+
+def install(monkeypatch):
+    from whisper_timestamped import _lib, alignment, capture
+
+    monkeypatch.setattr(_lib, "require_gpu", lambda device, what="": None)
+    monkeypatch.setattr(_lib, "_need_cuda", lambda t, name: None)
+
+    def write(self, layer_index, qk, row):
+        heads, slots = self._heads[layer_index].long(), self._slots[layer_index].long()
+        if heads.numel():
+            self.buf[slots, row] = qk[0, heads, -1].to(self.buf.dtype)
+    monkeypatch.setattr(capture.QKCaptureRing, "write", write)
+
+    def logprob_gather(logits, tokens, suppress=None):
+        return O.token_logprob_gather_ref(logits.float(), np.asarray(tokens, dtype=np.int64),
+                                          None if suppress is None else suppress.bool())
+    monkeypatch.setattr(_lib, "logprob_gather", logprob_gather)
+
+    def find_start_padding(mel):
+        out = []
+        for b in range(mel.shape[0]):
+            r = O.find_start_padding_ref(mel[b:b + 1])
+            out.append(-1 if r is None else int(r))
+        return torch.tensor(out, dtype=torch.int32)
+    monkeypatch.setattr(_lib, "find_start_padding", find_start_padding)
+
+    def logmel(pcm, mel_fb, n_valid_samples=None, n_frames=3000):
+        B = pcm.shape[0]
+        M = mel_fb.shape[0]
+        mel = torch.zeros((B, M, n_frames))
+        gmax = torch.zeros(B)
+        for b in range(B):
+            n = pcm.shape[1] if n_valid_samples is None else int(n_valid_samples[b])
+            m = O.log_mel_spectrogram_ref(pcm[b, :n], M)
+            k = min(m.shape[-1], n_frames)
+            mel[b, :, :k] = m[:, :k]
+        return mel, gmax
+    monkeypatch.setattr(_lib, "logmel", logmel)
+
+    def run(self):
+        out = []
+        for u in self.units:
+            sel = u.qk[:, :, u.start_token:u.end_token].contiguous().numpy()
+            pad = u.pad_from if u.pad_from >= 0 else None
+            cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
+            r = O.dtw_ref(cost)
+            jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
+            out.append(alignment.finish_unit(u, jumps, cost.astype(np.float32)))
+        return out
+    monkeypatch.setattr(alignment.AlignmentBatch, "run", run)

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/transcribe_cases.json by running THE REFERENCE'S OWN
+``transcribe_timestamped`` (/root/reference/whisper_timestamped/transcribe.py,
+unmodified) in the build container, on the CPU, against
+
+  * ``tests/whisper_double`` registered as the ``whisper`` package (the real
+    openai-whisper is not installed; see that package's docstring), with
+    random-initialised models and SCRIPTED sampling so that every branch of the
+    hook state machine is reached deterministically;
+  * a ``dtw`` stub backed by oracle/dtw_ref.c (dtw-python is not installed).
+
+The GPU tests (tests/test_gpu_transcribe.py) rebuild the same model / audio /
+script from the case parameters and compare this repository's ``transcribe``
+with the stored reference output.
+
+Run:  python tests/golden/make_golden_transcribe.py      (needs /root/reference)
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+REF = "/root/reference/whisper_timestamped/transcribe.py"
+OUT = os.path.join(HERE, "transcribe_cases.json")
+
+
+# --------------------------------------------------------------------------- shared with the GPU tests
+def text_ids(seed, n):
+    """Text-token ids that no logit filter suppresses (the KAT pieces + synthetic ids)."""
+    import whisper_double.tokenizer as T
+    tk = T.get_tokenizer(True, language="en")
+    banned = set(tk.non_speech_tokens) | {220}
+    pool = [t for t in (6455, 2232, 286, 2041, 8660, 291, 808, 493, 365, 445, 718, 505, 458, 4666, 1022, 6992, 631, 7282,
+                        1956, 871, 8208, 517, 5977, 7418) if t not in banned]
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        r = rng.rand()
+        if r < 0.5:
+            out.append(int(pool[rng.randint(len(pool))]))
+        elif r < 0.9:
+            t = int(rng.randint(300, 40000))
+            out.append(t if t not in banned else 300)
+        else:
+            out.append(int([11, 13][rng.randint(2)]))      # "," "."
+    return out
+
+
+def window_script(ts0, eot, segments, ending="eot"):
+    """segments: [(start_frame, [text ids], end_frame)].  Whisper's pattern: <|s|> text <|e|><|s'|> text <|e'|> ... ;
+    ending: "eot" -> ... <|e|> eot ("single timestamp ending"); "pair" -> ... <|e|><|e|> eot (no speech after);
+    "noend" -> text then eot (no closing timestamp); "limit" -> no eot at all (decoder hits sample_len)."""
+    toks = []
+    for k, (s, text, e) in enumerate(segments):
+        toks.append(ts0 + s)
+        toks.extend(text)
+        last = k == len(segments) - 1
+        if last and ending == "noend":
+            break
+        if last and ending == "limit":
+            break
+        toks.append(ts0 + e)
+        if last and ending == "pair":
+            toks.append(ts0 + e)
+    if ending != "limit":
+        toks.append(eot)
+    return toks
+
+
+def case_list():
+    C = []
+    ML, EN = 50364, 50363           # timestamp_begin
+    EOT_ML, EOT_EN = 50257, 50256
+
+    def seg(seed, s, n, e):
+        return (s, text_ids(seed, n), e)
+
+    C.append(dict(name="one_window_two_segments", model="tiny", audio_s=12.0, audio_seed=1,
+                  opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, [seg(1, 10, 7, 180), seg(2, 200, 9, 520)], "eot")]))
+    C.append(dict(name="two_windows_prompted", model="tiny", audio_s=47.0, audio_seed=2,
+                  opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, [seg(3, 0, 8, 300), seg(4, 300, 6, 700), seg(5, 720, 10, 1300)], "pair"),
+                          window_script(ML, EOT_ML, [seg(6, 25, 6, 400), seg(7, 410, 5, 800)], "eot")]))
+    C.append(dict(name="eot_without_end_timestamp", model="tiny", audio_s=9.0, audio_seed=3,
+                  opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, [seg(8, 5, 6, 150), seg(9, 160, 7, 0)], "noend")]))
+    C.append(dict(name="decoding_limit", model="tiny", audio_s=20.0, audio_seed=4,
+                  opts=dict(language="en", sample_len=40),
+                  script=[window_script(ML, EOT_ML, [seg(10, 12, 9, 260), seg(11, 270, 40, 0)], "limit")[:40]]))
+    C.append(dict(name="language_detection", model="tiny", audio_s=8.0, audio_seed=5,
+                  opts=dict(language=None),
+                  script=[window_script(ML, EOT_ML, [seg(12, 20, 8, 350)], "eot")]))
+    C.append(dict(name="english_only_model", model="tiny.en", audio_s=10.0, audio_seed=6,
+                  opts=dict(language="en"),
+                  script=[window_script(EN, EOT_EN, [seg(13, 8, 6, 210), seg(14, 230, 8, 480)], "eot")]))
+    C.append(dict(name="no_trust_whisper_timestamps", model="tiny", audio_s=36.0, audio_seed=7,
+                  opts=dict(language="en", trust_whisper_timestamps=False),
+                  script=[window_script(ML, EOT_ML, [seg(15, 6, 7, 280), seg(16, 300, 8, 690), seg(17, 700, 6, 1100)], "pair"),
+                          window_script(ML, EOT_ML, [seg(18, 15, 9, 500)], "eot")]))
+    C.append(dict(name="punctuation_options", model="tiny", audio_s=11.0, audio_seed=8,
+                  opts=dict(language="en", include_punctuation_in_confidence=True, remove_punctuation_from_words=True),
+                  script=[window_script(ML, EOT_ML, [(4, [6455, 11, 2232, 11, 286, 2041, 13], 240),
+                                                     (250, [8660, 291, 808, 13, 13, 493], 500)], "eot")]))
+    # (compute_word_confidence=False together with no_speech_threshold=None crashes the reference itself:
+    #  chunk_logprobs stays empty, transcribe.py:526 -- so only the first is switched off here)
+    C.append(dict(name="no_confidence", model="tiny", audio_s=7.0, audio_seed=9,
+                  opts=dict(language="en", compute_word_confidence=False),
+                  script=[window_script(ML, EOT_ML, [seg(19, 3, 9, 330)], "eot")]))
+    C.append(dict(name="no_speech_skip", model="tiny", audio_s=40.0, audio_seed=10,
+                  opts=dict(language="en", no_speech_threshold=1e-12, logprob_threshold=-0.05),
+                  script=[window_script(ML, EOT_ML, [seg(20, 10, 6, 300), seg(21, 310, 7, 800)], "pair"),
+                          window_script(ML, EOT_ML, [seg(22, 5, 5, 200)], "eot")]))
+    C.append(dict(name="all_heads_top_layers", model="tiny", audio_s=9.0, audio_seed=11,
+                  opts=dict(language="en", word_alignment_most_top_layers=2),
+                  script=[window_script(ML, EOT_ML, [seg(23, 7, 8, 300)], "eot")]))
+    C.append(dict(name="disfluencies_and_empty_words", model="tiny", audio_s=14.0, audio_seed=12,
+                  opts=dict(language="en", detect_disfluencies=True, remove_empty_words=True, min_word_duration=0.04),
+                  script=[window_script(ML, EOT_ML, [seg(24, 2, 12, 420), seg(25, 440, 10, 690)], "eot")]))
+    C.append(dict(name="norefine_french", model="tiny", audio_s=10.0, audio_seed=13,
+                  opts=dict(language="fr", refine_whisper_precision=0.0),
+                  script=[window_script(ML, EOT_ML, [(5, [11771, 17134, 4666, 1022, 875, 2557, 68], 260),
+                                                     (270, [6992, 631, 269, 6, 377, 409, 7282], 490)], "eot")]))
+    # ---- naive strategy (transcribe, then teacher-forced re-run) -------------------------------------
+    C.append(dict(name="naive_greedy", model="tiny", audio_s=12.0, audio_seed=14,
+                  opts=dict(language="en", naive_approach=True),
+                  script=[window_script(ML, EOT_ML, [seg(26, 10, 7, 200), seg(27, 210, 8, 560)], "eot")]))
+    C.append(dict(name="naive_beam", model="tiny", audio_s=41.0, audio_seed=15,
+                  opts=dict(language="en", beam_size=2),
+                  script=[window_script(ML, EOT_ML, [seg(28, 0, 6, 400), seg(29, 420, 7, 1100)], "pair"),
+                          window_script(ML, EOT_ML, [seg(30, 12, 6, 380)], "eot")]))
+    C.append(dict(name="naive_no_trust", model="tiny", audio_s=13.0, audio_seed=16,
+                  opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False,
+                            include_punctuation_in_confidence=True),
+                  script=[window_script(ML, EOT_ML, [seg(31, 5, 8, 250), (260, [6455, 11, 2232, 13], 600)], "eot")]))
+    C.append(dict(name="naive_language_detection", model="tiny", audio_s=8.0, audio_seed=17,
+                  opts=dict(language=None, temperature=(0.0, 0.4)),
+                  script=[window_script(ML, EOT_ML, [seg(32, 6, 7, 330)], "eot")]))
+    return C
+
+
+def build_case(c, device="cpu"):
+    """-> (model, audio tensor on the CPU, Script)"""
+    import whisper_double as W
+    from whisper_double.decoding import Script
+    model = W.build_model(c["model"], seed=c.get("model_seed", 0), device=device)
+    g = torch.Generator().manual_seed(1000 + c["audio_seed"])
+    n = int(round(c["audio_s"] * 16000))
+    t = torch.arange(n) / 16000.0
+    audio = 0.05 * torch.randn(n, generator=g) + 0.1 * torch.sin(2 * np.pi * 220.0 * t) * (torch.sin(2 * np.pi * 0.7 * t) > 0)
+    return model, audio.float(), Script(c["script"])
+
+
+def public_view(result):
+    """What the parity test compares: the JSON surface (times, texts, confidences)."""
+    out = dict(text=result["text"], language=result.get("language"), segments=[])
+    if "language_probs" in result:
+        lp = result["language_probs"]
+        top = sorted(lp, key=lp.get, reverse=True)[:3]
+        out["language_probs_top"] = {k: lp[k] for k in top}
+    for s in result["segments"]:
+        seg = {k: s[k] for k in ("id", "seek", "start", "end", "text", "tokens", "temperature", "avg_logprob",
+                                 "compression_ratio", "no_speech_prob") if k in s}
+        if "confidence" in s:
+            seg["confidence"] = s["confidence"]
+        seg["words"] = [dict(w) for w in s.get("words", [])]
+        out["segments"].append(seg)
+    return out
+
+
+# --------------------------------------------------------------------------- reference loading
+def load_reference():
+    import whisper_double as W
+    from oracle import align_ref as O
+    W.install()
+    d = types.ModuleType("dtw")
+    sp = types.ModuleType("dtw.stepPattern")
+    sp.symmetric1 = "symmetric1"
+    d.stepPattern = sp
+    d.dtw = lambda x, step_pattern=None, **kw: O.dtw_ref(x)
+    sys.modules.update({"dtw": d, "dtw.stepPattern": sp})
+    spec = importlib.util.spec_from_file_location("ref_transcribe", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    from whisper_double.decoding import set_script
+    ref = load_reference()
+    only = set(sys.argv[1:])
+    cases = []
+    if only and os.path.exists(OUT):
+        cases = json.load(open(OUT))
+    done = {c["name"]: c for c in cases}
+    for c in case_list():
+        if only and c["name"] not in only:
+            continue
+        model, audio, script = build_case(c)
+        set_script(script)
+        try:
+            result = ref.transcribe_timestamped(model, audio, fp16=False, **c["opts"])
+        finally:
+            set_script(None)
+        rec = dict(c)
+        rec["expected"] = json.loads(json.dumps(public_view(result), default=float))
+        rec["recorded"] = script.record
+        done[c["name"]] = rec
+        nw = sum(len(s["words"]) for s in rec["expected"]["segments"])
+        print(f"{c['name']:32s} segments={len(rec['expected']['segments'])} words={nw} windows={len(script.record)}")
+    order = [c["name"] for c in case_list()]
+    with open(OUT, "w", encoding="utf-8") as f:
+        json.dump([done[n] for n in order if n in done], f, ensure_ascii=False, indent=0)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -396,3 +396,31 @@ def test_logmel_vs_oracle():
         # exact zeros in the padding, so that find_start_padding sees it
         assert (mel[2][:, valid[2] // 160:] == 0).all()
         assert L.find_start_padding(mel.to(DEV)).cpu().tolist()[2] == valid[2] // 160
+
+
+def test_reference_side_stub():
+    """Executes the ctypes stub printed in INTEGRATION.md section 3 (what a maintainer of the reference would
+    add) against the oracle, so the documented binding cannot rot."""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md"), encoding="utf-8").read()
+    code = re.search(r"```python\n# --- whisper_timestamped/transcribe.py \(reference side\).*?\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libwtalign.so")', f'ctypes.CDLL({_lib().LIB_PATH!r})')
+    ns = {}
+    exec(code, ns)
+    L, H, T = 6, 8, 21
+    heads = [(3, 1), (4, 2), (4, 3), (4, 7), (5, 1), (5, 2), (5, 4), (5, 6)]
+    qk = synth.synth_qk(77, L * H, T, lo=100, hi=420).reshape(L, H, T, 1500)
+    mask = torch.zeros(L, H, dtype=torch.bool)
+    for l, h in heads:
+        mask[l, h] = True
+    start, end, max_duration = 90, 430, 200
+    jumps, cost = ns["_wt_jumps"](torch.from_numpy(qk).to(DEV), start, end, mask.to_sparse(), max_duration)
+    sel = O.select_heads_ref([torch.from_numpy(qk[l:l + 1]) for l in range(L)], start, end, np.array(heads))
+    want_cost = O.cost_matrix_ref(sel, 9, 1.0, max_duration, start)
+    r = O.dtw_ref(want_cost)
+    want = O.jumps_from_path(r.index1s, r.index2s)
+    got_cost = cost.cpu().numpy().reshape(T, end - start)
+    np.testing.assert_allclose(got_cost, want_cost, rtol=2e-5, atol=2e-7)
+    assert np.abs(jumps.astype(np.int64) - want).max() <= 1

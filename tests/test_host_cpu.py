@@ -114,3 +114,27 @@ def test_words_from_fixture_jumps():
         got = [dict(text=w["text"], start=w["start"], end=w["end"], tokens=w["tokens"],
                     tokens_indices=[int(x) for x in w["tokens_indices"]]) for w in got]
         assert got == c["words"], c["name"]
+
+
+def test_ensure_increasing_positions_vs_reference_fixture():
+    """postfix_cases.json: outputs of the reference's ensure_increasing_positions (transcribe.py:2265-2295)."""
+    import copy
+    from whisper_timestamped.postprocess import ensure_increasing_positions
+    cases = json.load(open(os.path.join(G, "postfix_cases.json")))
+    assert cases
+    for c in cases:
+        words = copy.deepcopy(c["input"])
+        if c["expected"] == "AssertionError":
+            with pytest.raises(AssertionError):
+                ensure_increasing_positions(words, min_duration=c["min_duration"])
+        else:
+            assert ensure_increasing_positions(words, min_duration=c["min_duration"]) == c["expected"]
+
+
+def test_alignment_head_tables_match_reference_dumps():
+    """ALIGNMENT_HEADS equals the packed masks the reference carries (transcribe.py:2343-2357); SURVEY.md 8 table."""
+    from whisper_timestamped.transcribe import ALIGNMENT_HEADS, alignment_heads_for
+    assert ALIGNMENT_HEADS["base"][2] == [(3, 1), (4, 2), (4, 3), (4, 7), (5, 1), (5, 2), (5, 4), (5, 6)]
+    assert len(ALIGNMENT_HEADS["small.en"][2]) == 19 and len(ALIGNMENT_HEADS["large-v2"][2]) == 23
+    ah = alignment_heads_for("large-v3", 32, 20)
+    assert ah.is_sparse and ah.coalesce().indices().T.tolist()[0] == [7, 0]

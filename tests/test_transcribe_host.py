@@ -1,0 +1,70 @@
+"""Host logic of transcribe() (hook state machine, naive driver, confidence glue,
+post-processors) against the REFERENCE'S OWN OUTPUT (tests/golden/transcribe_cases.json,
+produced by running /root/reference's transcribe_timestamped on the same whisper double).
+
+No GPU here: the five kernel entry points are replaced by the CPU oracle
+(tests/cpu_kernel_standin.py), so what is checked is every decision of the host
+layer.  With oracle numerics the result must equal the reference's exactly.
+The same cases run with the real HIP kernels in tests/test_gpu_transcribe.py.
+"""
+import copy
+import json
+import os
+
+import pytest
+
+import cpu_kernel_standin
+from golden import make_golden_transcribe as G
+
+CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "transcribe_cases.json"), encoding="utf-8"))
+
+
+def run_case(c, device="cpu"):
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_script
+    W.install()
+    import whisper_timestamped as wt
+    model, audio, _ = G.build_case(c, device=device)
+    script = set_script(Script(c["recorded"]))       # replay exactly what the reference run sampled
+    try:
+        result = wt.transcribe(model, audio, fp16=False, **c["opts"])
+    finally:
+        set_script(None)
+    assert script.record == c["recorded"]
+    return json.loads(json.dumps(G.public_view(result), default=float))
+
+
+def compare(got, exp, time_tol, conf_tol, logprob_tol=1e-4):
+    assert got["text"] == exp["text"]
+    assert got["language"] == exp["language"]
+    assert len(got["segments"]) == len(exp["segments"])
+    if "language_probs_top" in exp:
+        assert list(got["language_probs_top"]) == list(exp["language_probs_top"])
+        for k, v in exp["language_probs_top"].items():
+            assert abs(got["language_probs_top"][k] - v) <= 1e-4
+    worst_t = worst_c = 0.0
+    for gs, es in zip(got["segments"], exp["segments"]):
+        for k in ("id", "seek", "text", "tokens", "temperature"):
+            assert gs.get(k) == es.get(k), (k, gs.get(k), es.get(k))
+        for k in ("avg_logprob", "no_speech_prob", "compression_ratio"):
+            assert abs(gs[k] - es[k]) <= logprob_tol * max(1.0, abs(es[k])), (k, gs[k], es[k])
+        assert ("confidence" in gs) == ("confidence" in es)
+        if "confidence" in es:
+            worst_c = max(worst_c, abs(gs["confidence"] - es["confidence"]))
+        worst_t = max(worst_t, abs(gs["start"] - es["start"]), abs(gs["end"] - es["end"]))
+        assert [w["text"] for w in gs["words"]] == [w["text"] for w in es["words"]]
+        for gw, ew in zip(gs["words"], es["words"]):
+            assert set(gw) == set(ew), (gw, ew)
+            worst_t = max(worst_t, abs(gw["start"] - ew["start"]), abs(gw["end"] - ew["end"]))
+            if "confidence" in ew:
+                worst_c = max(worst_c, abs(gw["confidence"] - ew["confidence"]))
+    assert worst_t <= time_tol + 1e-9, f"max |dt| = {worst_t}"
+    assert worst_c <= conf_tol + 1e-9, f"max |dconfidence| = {worst_c}"
+    return worst_t, worst_c
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_transcribe_host_logic_equals_reference(case, monkeypatch):
+    cpu_kernel_standin.install(monkeypatch)
+    got = run_case(copy.deepcopy(case))
+    compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)

@@ -61,6 +61,8 @@ int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int3
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, float *, hipStream_t);
 int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
 int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
+int capture_rows(const void *, int, int, int, int, const int32_t *, const int32_t *, int, void *, int, int64_t, int64_t,
+                 hipStream_t);
 
 }  // namespace wt
 
@@ -83,6 +85,12 @@ int wt_shutdown(void) {
     }
     wt::g_arena.clear();
     return WT_OK;
+}
+
+int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ctx, const int32_t *heads, const int32_t *slots,
+                    int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row, void *stream) {
+    return wt::capture_rows(qk, qk_dtype, n_heads, n_q, n_ctx, heads, slots, n_sel, ring, ring_dtype, ring_rows, row,
+                            (hipStream_t)stream);
 }
 
 int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,

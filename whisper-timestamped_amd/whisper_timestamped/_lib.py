@@ -27,7 +27,7 @@ SEG_DTYPE = np.dtype([
 assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
-           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch"]
+           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows"]
 
 
 class WtError(RuntimeError):
@@ -56,6 +56,7 @@ def load():
     L.wt_find_start_padding_batch.argtypes = [vp, i32, i32, i32, vp, vp]
     L.wt_logprob_gather_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, i32, vp, vp]
     L.wt_logmel_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp]
+    L.wt_capture_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, vp]
     for n in EXPORTS[3:]:
         getattr(L, n).restype = i32
     _lib = L
@@ -75,6 +76,11 @@ def _stream() -> int:
 def _need_cuda(t: torch.Tensor, name: str):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise WtError(f"{name} must be a CUDA(HIP) tensor: the alignment kernels only run on the GPU")
+
+
+def require_gpu(device, what="the MI355X alignment path"):
+    if torch.device(device).type != "cuda":
+        raise WtError(f"{what} needs the model and its tensors on the GPU (there is no CPU fallback)")
 
 
 def _ptr(t):

@@ -86,9 +86,15 @@ def _gather_heads(attention_weights, pairs, device):
 
 def prepare_unit(tokens, attention_weights, tokenizer, use_space=True, mfcc=None, refine_whisper_precision_nframes=0,
                  remove_punctuation_from_words=False, include_punctuation_in_timing=False, unfinished_decoding=False,
-                 alignment_heads=None, detect_disfluencies=True, start_of_padding="auto", device=None, tag=None):
+                 alignment_heads=None, detect_disfluencies=True, start_of_padding="auto", device=None, tag=None,
+                 qk_selected=None):
     """Host part of perform_word_alignment up to the kernel call.  Returns an
-    AlignmentUnit, or None for the empty segment of transcribe.py:1478-1481."""
+    AlignmentUnit, or None for the empty segment of transcribe.py:1478-1481.
+
+    ``attention_weights`` is the reference's list of per-layer (1,H,T,n_ctx)
+    tensors; alternatively ``qk_selected`` is an already head-selected
+    (A_sel, T, n_ctx) GPU tensor (e.g. a QKCaptureRing view) and
+    ``attention_weights`` / ``alignment_heads`` are ignored."""
     tokens = [int(t) for t in tokens]
     show = lambda: tokenizer.decode_with_timestamps(tokens)  # noqa: E731
     win = frame_window(tokens, tokenizer.timestamp_begin, refine_whisper_precision_nframes, show)
@@ -96,34 +102,45 @@ def prepare_unit(tokens, attention_weights, tokenizer, use_space=True, mfcc=None
         return None
     start_token, end_token = win
 
-    for w in attention_weights:
-        assert w.shape[-2] == len(tokens), f"Attention weights have wrong shape: {w.shape[-2]} (expected {len(tokens)})."
+    if qk_selected is not None:
+        assert qk_selected.shape[-2] == len(tokens), \
+            f"Attention weights have wrong shape: {qk_selected.shape[-2]} (expected {len(tokens)})."
+    else:
+        for w in attention_weights:
+            assert w.shape[-2] == len(tokens), f"Attention weights have wrong shape: {w.shape[-2]} (expected {len(tokens)})."
     num_frames = end_token - start_token
     if len(tokens) > num_frames:                               # transcribe.py:1516-1535
         logger.warning(f"Too much text ({len(tokens)} tokens) for the given number of frames ({num_frames}) in: "
                        f"{show()}\nThe end of the text will be removed.")
         keep = num_frames - 1
+        if qk_selected is not None:
+            qk_selected = torch.cat([qk_selected[:, :keep], qk_selected[:, -1:]], dim=1)
+        else:
+            attention_weights = [torch.cat([torch.as_tensor(w)[:, :, :keep, :], torch.as_tensor(w)[:, :, -1:, :]], dim=-2)
+                                 for w in attention_weights]
         return prepare_unit(
-            tokens[:keep] + [tokens[-1]],
-            [torch.cat([torch.as_tensor(w)[:, :, :keep, :], torch.as_tensor(w)[:, :, -1:, :]], dim=-2)
-             for w in attention_weights],
+            tokens[:keep] + [tokens[-1]], attention_weights,
             tokenizer, use_space=use_space, mfcc=mfcc,
             refine_whisper_precision_nframes=refine_whisper_precision_nframes,
             remove_punctuation_from_words=remove_punctuation_from_words,
             include_punctuation_in_timing=False,               # the reference's recursion drops this argument
             unfinished_decoding=True, alignment_heads=alignment_heads, detect_disfluencies=detect_disfluencies,
-            start_of_padding=start_of_padding, device=device, tag=tag)
+            start_of_padding=start_of_padding, device=device, tag=tag, qk_selected=qk_selected)
 
     splitter = split_tokens_on_spaces if use_space else split_tokens_on_unicode
     words, word_pieces, word_ids = splitter(tokens, tokenizer, remove_punctuation_from_words=remove_punctuation_from_words)
     punct_counts = trailing_punctuation_counts(word_pieces, include_punctuation_in_timing)
 
-    if device is None:
-        device = next((w.device for w in attention_weights if isinstance(w, torch.Tensor) and w.is_cuda),
-                      torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
-    if device is None:
-        raise _lib.WtError("no GPU: the word-alignment kernels have no CPU fallback")
-    qk = _gather_heads(attention_weights, head_pairs(alignment_heads), device)
+    if qk_selected is not None:
+        _lib._need_cuda(qk_selected, "qk_selected")
+        qk, device = qk_selected, qk_selected.device
+    else:
+        if device is None:
+            device = next((w.device for w in attention_weights if isinstance(w, torch.Tensor) and w.is_cuda),
+                          torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        if device is None:
+            raise _lib.WtError("no GPU: the word-alignment kernels have no CPU fallback")
+        qk = _gather_heads(attention_weights, head_pairs(alignment_heads), device)
     assert end_token <= qk.shape[-1]
 
     if start_of_padding == "auto":
@@ -169,7 +186,7 @@ class AlignmentBatch:
         descs = _lib.make_descs(len(units))
         n_sel = units[0].qk.shape[0]
         for d, u in zip(descs, units):
-            assert u.qk.dtype == dt and u.qk.device == dev and u.qk.shape[0] == n_sel and u.qk.is_contiguous()
+            assert u.qk.dtype == dt and u.qk.device == dev and u.qk.shape[0] == n_sel and u.qk.stride(2) == 1
             off = u.qk.data_ptr() - base
             assert off % esz == 0
             d["qk_offset"] = off // esz

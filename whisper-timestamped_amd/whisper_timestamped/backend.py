@@ -1,0 +1,80 @@
+"""Access to the speech-recognition backend (openai-whisper).
+
+whisper-timestamped does not contain a Whisper model: it drives
+``openai-whisper`` through forward hooks and a few module-level names
+(/root/reference/whisper_timestamped/transcribe.py:14,42-58).  The same holds
+here; the import is lazy so that the alignment kernels and
+``perform_word_alignment`` are usable without the package.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+
+
+def whisper():
+    try:
+        import whisper as _w
+    except ImportError as err:  # pragma: no cover - depends on the environment
+        raise ImportError("transcribe()/load_model() need the openai-whisper package (or a compatible module "
+                          "registered as `whisper`); the alignment kernels themselves do not") from err
+    return _w
+
+
+def whisper_version() -> str:
+    return getattr(whisper(), "__version__", "")
+
+
+def ge_20230306() -> bool:   # segment tokens include the timestamp tokens, model.alignment_heads exists
+    return whisper_version() >= "20230306"
+
+
+@contextmanager
+def attention_weights_exposed():
+    """openai-whisper >= 20240930 returns qk=None from the fused SDPA path; the
+    reference wraps decoding in whisper.model.disable_sdpa() (transcribe.py:49-58,900)."""
+    w = whisper()
+    ctx = getattr(getattr(w, "model", None), "disable_sdpa", None)
+    if ctx is None or whisper_version() < "20240930":
+        yield
+    else:
+        with ctx():
+            yield
+
+
+def get_tokenizer(model, task="transcribe", language="en"):
+    """transcribe.py:1406-1426 (openai-whisper branch)."""
+    tk = whisper().tokenizer
+    try:
+        return tk.get_tokenizer(model.is_multilingual, num_languages=getattr(model, "num_languages", 99), task=task,
+                                language=language)
+    except TypeError:  # older openai-whisper: no num_languages
+        return tk.get_tokenizer(model.is_multilingual, task=task, language=language)
+
+
+_NOT_DECODING_OPTIONS = ("no_speech_threshold", "logprob_threshold", "compression_ratio_threshold",
+                         "condition_on_previous_text", "verbose")
+
+
+def get_logit_filters(model, whisper_options, prompt=None):
+    """The logit filters whisper itself applies while sampling, rebuilt for a given prompt so that
+    ``sample_begin`` matches (transcribe.py:1371-1404)."""
+    w = whisper()
+    opts = {k: v for k, v in whisper_options.items() if k not in _NOT_DECODING_OPTIONS}
+    if "initial_prompt" in opts:
+        first_prompt = opts.pop("initial_prompt")
+        if prompt is None:
+            prompt = first_prompt
+    if prompt is not None:
+        opts["prompt"] = prompt
+    options = w.DecodingOptions(without_timestamps=False, max_initial_timestamp=1.0, prefix=None, suppress_blank=True, **opts)
+    return w.decoding.DecodingTask(model, options).logit_filters
+
+
+def norm_language(language):
+    if language is None:
+        return "en"
+    return whisper().tokenizer.TO_LANGUAGE_CODE.get(language.lower(), language)
+
+
+def should_use_space(language) -> bool:
+    return norm_language(language) not in ["zh", "ja", "th", "lo", "my", "yue"]

@@ -1,0 +1,108 @@
+"""Device-side data plane of the decode-time hooks.
+
+The reference's hooks move data to the host once per token:
+``hook_attention_weights`` does ``w[:, :, -1:, :].cpu()`` for every hooked layer
+(/root/reference/whisper_timestamped/transcribe.py:783-793) and
+``hook_output_logits`` keeps one full ``log_softmax`` vector (V floats) per step
+(:849-881).  Here both live in preallocated device rings:
+
+* ``QKCaptureRing`` -- (A_sel, capacity, n_ctx): only the alignment heads are
+  stored; the hook calls ``wt_capture_rows`` (one async launch, no sync).
+  A segment is a list of ring rows; contiguous rows are handed to the cost
+  kernel as a strided view (no copy).
+* ``LogitsRing`` -- (capacity, V) fp32 *filtered logits* per step.  The
+  log-softmax is never materialised: the chosen-token log-probabilities of a
+  whole window are produced by one ``wt_logprob_gather_batch`` at flush time.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def layer_head_slots(alignment_heads_pairs, n_hooked_layers: int, n_heads: int):
+    """Per hooked layer: (heads, slots).  Slot order = order of the reference's
+    head stacking: rows of ``alignment_heads.indices().T`` (COO, layer-major),
+    or layer-major all heads when no alignment heads are known
+    (transcribe.py:1542-1545)."""
+    per_layer = [([], []) for _ in range(n_hooked_layers)]
+    if alignment_heads_pairs is None:
+        slot = 0
+        for l in range(n_hooked_layers):
+            for h in range(n_heads):
+                per_layer[l][0].append(h)
+                per_layer[l][1].append(slot)
+                slot += 1
+        return per_layer, slot
+    for slot, (l, h) in enumerate(alignment_heads_pairs):
+        assert 0 <= l < n_hooked_layers and 0 <= h < n_heads, f"alignment head ({l},{h}) outside the hooked layers"
+        per_layer[l][0].append(h)
+        per_layer[l][1].append(slot)
+    return per_layer, len(alignment_heads_pairs)
+
+
+class QKCaptureRing:
+    def __init__(self, device, alignment_heads_pairs, n_hooked_layers: int, n_heads: int, n_ctx: int = 1500,
+                 capacity: int = 448, dtype=torch.float32):
+        per_layer, self.n_slots = layer_head_slots(alignment_heads_pairs, n_hooked_layers, n_heads)
+        self.device = torch.device(device)
+        self.n_ctx, self.capacity, self.n_heads = n_ctx, capacity, n_heads
+        self.buf = torch.zeros((self.n_slots, capacity, n_ctx), dtype=dtype, device=device)
+        self._dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[dtype]
+        self._heads = [torch.tensor(h, dtype=torch.int32, device=device) for h, _ in per_layer]
+        self._slots = [torch.tensor(s, dtype=torch.int32, device=device) for _, s in per_layer]
+        self._lib = _lib.load()
+
+    def write(self, layer_index: int, qk: torch.Tensor, row: int):
+        """qk: (1, H, n_q, n_ctx) QK logits of one layer; stores its last query row at ring row `row`."""
+        _lib._need_cuda(qk, "qk")
+        assert qk.dim() == 4 and qk.shape[0] == 1 and qk.shape[1] == self.n_heads and qk.shape[3] == self.n_ctx, qk.shape
+        if not qk.is_contiguous():
+            qk = qk.contiguous()
+        heads = self._heads[layer_index]
+        if heads.numel() == 0:
+            return
+        dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[qk.dtype]
+        rc = self._lib.wt_capture_rows(qk.data_ptr(), dt, qk.shape[1], qk.shape[2], self.n_ctx, heads.data_ptr(),
+                                       self._slots[layer_index].data_ptr(), heads.numel(), self.buf.data_ptr(), self._dt,
+                                       self.capacity, int(row), _lib._stream())
+        _lib._check(rc, "wt_capture_rows")
+
+    def rows(self, rows) -> torch.Tensor:
+        """(A_sel, len(rows), n_ctx): a strided VIEW when the rows are consecutive, else a device gather."""
+        rows = list(rows)
+        if rows and rows == list(range(rows[0], rows[0] + len(rows))):
+            return self.buf[:, rows[0]:rows[0] + len(rows)]
+        idx = torch.tensor(rows, dtype=torch.long, device=self.device)
+        return self.buf.index_select(1, idx)
+
+
+class LogitsRing:
+    def __init__(self, device, n_vocab: int, capacity: int = 448):
+        self.buf = torch.empty((capacity, n_vocab), dtype=torch.float32, device=device)
+        self.n = 0
+
+    def reset(self):
+        self.n = 0
+
+    def append(self, logits_row: torch.Tensor):
+        """logits_row: (V,) or (1,V) filtered logits (suppressed entries = -inf) of the step just computed."""
+        self.buf[self.n].copy_(logits_row.reshape(-1))
+        self.n += 1
+
+    def __len__(self):
+        return self.n
+
+    def argmax(self, row: int, lo: int = 0) -> int:
+        """argmax of log_softmax(row)[lo:] (+lo).  log_softmax is monotone: taken on the logits."""
+        if row < 0:
+            row += self.n
+        return int(torch.argmax(self.buf[row, lo:]).item()) + lo
+
+    def gather(self, tokens) -> torch.Tensor:
+        """fp32[n]: log_softmax(row k)[tokens[k]] for the first len(tokens) rows (one kernel, no (n,V) matrix)."""
+        n = len(tokens)
+        assert n <= self.n
+        tok = torch.as_tensor(tokens, dtype=torch.int32)
+        return _lib.logprob_gather(self.buf[:n], tok)
