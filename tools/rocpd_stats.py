@@ -30,13 +30,15 @@ def main():
         print(f"{short:70s} {len(d):6d} {sum(d)/len(d)/1e3:10.2f} {min(d)/1e3:10.2f} {max(d)/1e3:10.2f} "
               f"{sum(d)/1e6:10.3f} {100*sum(d)/max(tot,1):6.1f} {v[-1][1]:9d} {v[-1][2]:5d} {v[-1][3]:7d} {v[-1][4]:5d} {v[-1][5]:5d}")
     try:
-        pmc = db.execute("select s.kernel_name, p.name, avg(e.value), count(*) from rocpd_pmc_event e "
-                         "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
-                         "join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name, p.name").fetchall()
+        # one row per (dispatch, counter, dimension instance): sum over the instances of a dispatch, then average
+        pmc = db.execute("select kname, cname, avg(v), count(*) from (select s.kernel_name as kname, p.name as cname, "
+                         "sum(e.value) as v from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id "
+                         "join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s "
+                         "on d.kernel_id = s.id group by d.id, p.name) group by kname, cname").fetchall()
         if pmc:
-            print("\nPMC (average per dispatch)")
+            print("\nPMC (sum over counter instances, average per dispatch)")
             for name, cname, val, cnt in pmc:
-                print(f"{re.sub(r'[(].*', '', name)[:70]:70s} {cname:24s} {val:16.1f}  (n={cnt})")
+                print(f"{re.sub(r'[(].*', '', name)[:70]:70s} {cname:24s} {val:16.1f}  (dispatches={cnt})")
     except sqlite3.Error as e:
         print("no pmc:", e)
 

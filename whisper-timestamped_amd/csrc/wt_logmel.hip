@@ -24,9 +24,26 @@
 
 namespace wt {
 
-__constant__ float k_c20[20];
-__constant__ float k_s20[20];
 __constant__ float k_hann[400];
+
+// 20th roots of unity as compile-time constants: after full unrolling every use below is a literal, so the
+// zeros / ones / sign symmetries fold away at compile time.
+__host__ __device__ constexpr float c20(int m) {
+    m = ((m % 20) + 20) % 20;
+    if (m > 10) m = 20 - m;
+    return m == 0 ? 1.0f : m == 1 ? 0.9510565162951535f : m == 2 ? 0.8090169943749475f : m == 3 ? 0.5877852522924731f
+         : m == 4 ? 0.30901699437494745f : m == 5 ? 0.0f : m == 6 ? -0.30901699437494745f : m == 7 ? -0.5877852522924731f
+         : m == 8 ? -0.8090169943749475f : m == 9 ? -0.9510565162951535f : -1.0f;
+}
+__host__ __device__ constexpr float s20(int m) { return c20(m - 5); }  // sin(x) = cos(x - pi/2)
+// acc += x * w with w a compile-time constant (0 and +-1 cost nothing / one add)
+#define WT_MAC(acc, x, w)                         \
+    do {                                          \
+        constexpr float _w = (w);                 \
+        if (_w == 1.0f) acc += (x);               \
+        else if (_w == -1.0f) acc -= (x);         \
+        else if (_w != 0.0f) acc = fmaf((x), _w, acc); \
+    } while (0)
 __constant__ float2 k_w400[400];  // (cos, sin)(2*pi*k/400)
 
 constexpr int FPB = 12;             // frames per workgroup
@@ -87,13 +104,17 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ n_valid_samples,
                                                        const float *__restrict__ fb, const int *__restrict__ ws, int n_chunks,
                                                        int n_mels, int n_frames, float *__restrict__ mel_out) {
-    __shared__ float span[SPAN];
+    // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
+    // after stage 1 (a barrier separates them).
+    static_assert(FPB * 204 >= SPAN, "the span must fit in the pw buffer");
+    __shared__ float span[FPB * 204];
     __shared__ float2 w400[400];
     __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
-    __shared__ float pw[FPB][204];
     __shared__ float fbw[NNZ_CAP];
-    __shared__ int fb_lo[MAX_MELS], fb_n[MAX_MELS], fb_off[MAX_MELS];
+    __shared__ unsigned char fb_lo[MAX_MELS], fb_n[MAX_MELS];
+    __shared__ unsigned short fb_off[MAX_MELS];
     __shared__ int smax[4];
+    float (*pw)[204] = reinterpret_cast<float (*)[204]>(span);
 
     const int chunk = blockIdx.y;
     const int f0 = blockIdx.x * FPB;
@@ -124,27 +145,45 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         span[p] = x[i];
     }
     for (int p = tid; p < 400; p += 256) w400[p] = k_w400[p];
-    if (tid < n_mels) { fb_lo[tid] = g_lo[tid]; fb_n[tid] = g_n[tid]; fb_off[tid] = g_off[tid]; }
+    if (tid < n_mels) { fb_lo[tid] = (unsigned char)g_lo[tid]; fb_n[tid] = (unsigned char)g_n[tid]; fb_off[tid] = (unsigned short)g_off[tid]; }
     if (banded)
         for (int p = tid; p < nnz; p += 256) fbw[p] = g_w[p];
     __syncthreads();
 
     if (act) {
-        // ---- stage 1: radix-20 over n1 for this lane's n2 = u ----
+        // ---- stage 1: radix-20 over n1 for this lane's n2 = u (real input, k1 = 0..10) ----
+        // Pair n1 with 20-n1 (cos even, sin odd) and k1 with 10-k1 ((-1)^n1 symmetry): 108 MACs instead of 440.
         float a[20];
         const float *fr = span + slot * 160;
 #pragma unroll
         for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hw[n1];
+        float ep[10], em[10];
 #pragma unroll
-        for (int k1 = 0; k1 <= 10; ++k1) {
-            float sr = 0.f, si = 0.f;
-#pragma unroll
-            for (int n1 = 0; n1 < 20; ++n1) {
-                sr = fmaf(a[n1], k_c20[(n1 * k1) % 20], sr);
-                si = fmaf(a[n1], k_s20[(n1 * k1) % 20], si);
-            }
-            yp[slot][k1][u] = make_float2(sr, -si);
+        for (int n = 1; n < 10; ++n) {
+            ep[n] = a[n] + a[20 - n];
+            em[n] = a[n] - a[20 - n];
         }
+        const float base_e = a[0] + a[10], base_o = a[0] - a[10];   // a0 + (-1)^k1 a10
+        float sr[11], si[11];
+#define WT_S1(K)                                                                                          \
+        {                                                                                                 \
+            float Ae = 0.f, Ao = 0.f, Be = 0.f, Bo = 0.f;                                                 \
+            WT_MAC(Ae, ep[2], c20(2 * K)); WT_MAC(Ae, ep[4], c20(4 * K)); WT_MAC(Ae, ep[6], c20(6 * K));  \
+            WT_MAC(Ae, ep[8], c20(8 * K));                                                                \
+            WT_MAC(Ao, ep[1], c20(1 * K)); WT_MAC(Ao, ep[3], c20(3 * K)); WT_MAC(Ao, ep[5], c20(5 * K));  \
+            WT_MAC(Ao, ep[7], c20(7 * K)); WT_MAC(Ao, ep[9], c20(9 * K));                                 \
+            WT_MAC(Be, em[2], s20(2 * K)); WT_MAC(Be, em[4], s20(4 * K)); WT_MAC(Be, em[6], s20(6 * K));  \
+            WT_MAC(Be, em[8], s20(8 * K));                                                                \
+            WT_MAC(Bo, em[1], s20(1 * K)); WT_MAC(Bo, em[3], s20(3 * K)); WT_MAC(Bo, em[5], s20(5 * K));  \
+            WT_MAC(Bo, em[7], s20(7 * K)); WT_MAC(Bo, em[9], s20(9 * K));                                 \
+            const float base = (K & 1) ? base_o : base_e;                                                 \
+            sr[K] = base + Ae + Ao; sr[10 - K] = base + Ae - Ao;                                          \
+            si[K] = Be + Bo;        si[10 - K] = Bo - Be;                                                 \
+        }
+        WT_S1(0) WT_S1(1) WT_S1(2) WT_S1(3) WT_S1(4) WT_S1(5)
+#undef WT_S1
+#pragma unroll
+        for (int k1 = 0; k1 <= 10; ++k1) yp[slot][k1][u] = make_float2(sr[k1], -si[k1]);
     }
     __syncthreads();
     if (act) {
@@ -160,26 +199,47 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
             br[n2] = re * w.x + im * w.y;
             bi[n2] = im * w.x - re * w.y;
         }
+        // X[k2] = sum_n2 b[n2] e^{-2 pi i n2 k2 / 20}: pair n2 with 20-n2 and k2 with 10-k2 (216 MACs instead of 800)
+        float pr[10], pi_[10], mr[10], mi[10];
+#pragma unroll
+        for (int n = 1; n < 10; ++n) {
+            pr[n] = br[n] + br[20 - n]; mr[n] = br[n] - br[20 - n];
+            pi_[n] = bi[n] + bi[20 - n]; mi[n] = bi[n] - bi[20 - n];
+        }
+        const float bre = br[0] + br[10], bro = br[0] - br[10], bie = bi[0] + bi[10], bio = bi[0] - bi[10];
+        float xr[11], xi[11];
+#define WT_S2(K)                                                                                              \
+        {                                                                                                     \
+            float Ce = 0.f, Co = 0.f, Se = 0.f, So = 0.f, De = 0.f, Do = 0.f, Te = 0.f, To = 0.f;             \
+            WT_MAC(Ce, pr[2], c20(2 * K)); WT_MAC(Ce, pr[4], c20(4 * K)); WT_MAC(Ce, pr[6], c20(6 * K));      \
+            WT_MAC(Ce, pr[8], c20(8 * K));                                                                    \
+            WT_MAC(Co, pr[1], c20(1 * K)); WT_MAC(Co, pr[3], c20(3 * K)); WT_MAC(Co, pr[5], c20(5 * K));      \
+            WT_MAC(Co, pr[7], c20(7 * K)); WT_MAC(Co, pr[9], c20(9 * K));                                     \
+            WT_MAC(Se, mi[2], s20(2 * K)); WT_MAC(Se, mi[4], s20(4 * K)); WT_MAC(Se, mi[6], s20(6 * K));      \
+            WT_MAC(Se, mi[8], s20(8 * K));                                                                    \
+            WT_MAC(So, mi[1], s20(1 * K)); WT_MAC(So, mi[3], s20(3 * K)); WT_MAC(So, mi[5], s20(5 * K));      \
+            WT_MAC(So, mi[7], s20(7 * K)); WT_MAC(So, mi[9], s20(9 * K));                                     \
+            WT_MAC(De, pi_[2], c20(2 * K)); WT_MAC(De, pi_[4], c20(4 * K)); WT_MAC(De, pi_[6], c20(6 * K));   \
+            WT_MAC(De, pi_[8], c20(8 * K));                                                                   \
+            WT_MAC(Do, pi_[1], c20(1 * K)); WT_MAC(Do, pi_[3], c20(3 * K)); WT_MAC(Do, pi_[5], c20(5 * K));   \
+            WT_MAC(Do, pi_[7], c20(7 * K)); WT_MAC(Do, pi_[9], c20(9 * K));                                   \
+            WT_MAC(Te, mr[2], s20(2 * K)); WT_MAC(Te, mr[4], s20(4 * K)); WT_MAC(Te, mr[6], s20(6 * K));      \
+            WT_MAC(Te, mr[8], s20(8 * K));                                                                    \
+            WT_MAC(To, mr[1], s20(1 * K)); WT_MAC(To, mr[3], s20(3 * K)); WT_MAC(To, mr[5], s20(5 * K));      \
+            WT_MAC(To, mr[7], s20(7 * K)); WT_MAC(To, mr[9], s20(9 * K));                                     \
+            const float b_r = (K & 1) ? bro : bre, b_i = (K & 1) ? bio : bie;                                 \
+            xr[K] = b_r + (Ce + Co) + (Se + So); xr[10 - K] = b_r + (Ce - Co) + (So - Se);                    \
+            xi[K] = b_i + (De + Do) - (Te + To); xi[10 - K] = b_i + (De - Do) + (Te - To);                    \
+        }
+        WT_S2(0) WT_S2(1) WT_S2(2) WT_S2(3) WT_S2(4) WT_S2(5)
+#undef WT_S2
 #pragma unroll
         for (int k2 = 0; k2 < 10; ++k2) {
-            float xr = 0.f, xi = 0.f;
-#pragma unroll
-            for (int n2 = 0; n2 < 20; ++n2) {
-                const float c = k_c20[(n2 * k2) % 20], s = k_s20[(n2 * k2) % 20];
-                xr = fmaf(br[n2], c, fmaf(bi[n2], s, xr));
-                xi = fmaf(bi[n2], c, fmaf(-br[n2], s, xi));
-            }
-            const float mag = sqrtf(xr * xr + xi * xi);  // torch: stft.abs() ** 2
+            const float mag = sqrtf(xr[k2] * xr[k2] + xi[k2] * xi[k2]);  // torch: stft.abs() ** 2
             pw[slot][u + 20 * k2] = mag * mag;
         }
-        if (u == 0) {  // k = 200: W20^(10 n2) = (-1)^n2
-            float xr = 0.f, xi = 0.f;
-#pragma unroll
-            for (int n2 = 0; n2 < 20; ++n2) {
-                xr += (n2 & 1) ? -br[n2] : br[n2];
-                xi += (n2 & 1) ? -bi[n2] : bi[n2];
-            }
-            const float mag = sqrtf(xr * xr + xi * xi);
+        if (u == 0) {  // k = 200 (k1 = 0, k2 = 10)
+            const float mag = sqrtf(xr[10] * xr[10] + xi[10] * xi[10]);
             pw[slot][200] = mag * mag;
         }
     }
@@ -232,20 +292,14 @@ int scratch2(size_t bytes, void **out);
 
 static int upload_tables(hipStream_t st) {
     static bool done = false;
-    static float c20[20], s20[20], hann[400];
+    static float hann[400];
     static float2 w400[400];
     if (done) return WT_OK;
     const double PI = 3.14159265358979323846;
-    for (int k = 0; k < 20; ++k) {
-        c20[k] = (float)std::cos(2.0 * PI * k / 20.0);
-        s20[k] = (float)std::sin(2.0 * PI * k / 20.0);
-    }
     for (int n = 0; n < 400; ++n) {
         hann[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / 400.0));
         w400[n] = make_float2((float)std::cos(2.0 * PI * n / 400.0), (float)std::sin(2.0 * PI * n / 400.0));
     }
-    WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_c20), c20, sizeof(c20), 0, hipMemcpyHostToDevice, st));
-    WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_s20), s20, sizeof(s20), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_hann), hann, sizeof(hann), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_w400), w400, sizeof(w400), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipStreamSynchronize(st));  // once per process
