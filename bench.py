@@ -78,31 +78,85 @@ def make_workload(dev, cfg, seed):
 
 
 STAGES = ["logmel", "padding", "cost", "dtw", "logprob"]
+# kernels of each stage as rocprofv3 names them (profiles/*traffic.json keys)
+STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel"],
+                 "padding": ["find_start_padding_kernel"], "cost": ["rowmean_kernel", "colnorm_kernel", "fix00_kernel"],
+                 "dtw": ["dtw_kernel"], "logprob": ["logprob_gather_kernel"]}
 
 
-def run_step(w, ev=None):
-    """One pass of the hot path.  ev: optional list of 6 torch.cuda.Events (stage boundaries)."""
+def committed_traffic(stage):
+    """HBM bytes per launch of a stage's kernels from the newest committed PMC summary (profiles/*traffic.json:
+    rocprofv3 FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes of this same bench command).
+    PMC counters cannot be read from inside the timed run, so this is the committed measurement, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    tot = 0
+    for kname, v in data.items():
+        if any(k in kname for k in STAGE_KERNELS[stage]):
+            tot += int(v.get("hbm_bytes", 0))
+    return (tot or None), os.path.basename(files[-1])
+
+
+def _stage_calls(w):
     from whisper_timestamped import _lib
     L = _lib.load()
     cfg = w["cfg"]
     n, T, V = cfg["n_chunks"], cfg["T"], cfg["V"]
-    st = torch.cuda.current_stream().cuda_stream
-    if ev: ev[0].record()
-    _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, 0, w["fb"].data_ptr(), cfg["n_mels"], 3000,
-                                  w["mel"].data_ptr(), w["gmax"].data_ptr(), st), "wt_logmel_batch")
-    if ev: ev[1].record()
-    _lib._check(L.wt_find_start_padding_batch(w["mel"].data_ptr(), n, cfg["n_mels"], 3000, w["pad"].data_ptr(), st),
-                "wt_find_start_padding_batch")
-    if ev: ev[2].record()
-    _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
-                                w["head_idx"].data_ptr(), cfg["A"], 9, 1.0, w["cost"].data_ptr(), st), "wt_cost_batch")
-    if ev: ev[3].record()
-    _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
-                               w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
-    if ev: ev[4].record()
-    _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n * T, V, w["tokens"].data_ptr(), 0, 0,
-                                          w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
-    if ev: ev[5].record()
+
+    def logmel(st):
+        _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, 0, w["fb"].data_ptr(), cfg["n_mels"], 3000,
+                                      w["mel"].data_ptr(), w["gmax"].data_ptr(), st), "wt_logmel_batch")
+
+    def padding(st):
+        _lib._check(L.wt_find_start_padding_batch(w["mel"].data_ptr(), n, cfg["n_mels"], 3000, w["pad"].data_ptr(), st),
+                    "wt_find_start_padding_batch")
+
+    def cost(st):
+        _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+                                    w["head_idx"].data_ptr(), cfg["A"], 9, 1.0, w["cost"].data_ptr(), st), "wt_cost_batch")
+
+    def dtw(st):
+        _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+                                   w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
+
+    def logprob(st):
+        _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n * T, V, w["tokens"].data_ptr(), 0, 0,
+                                              w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
+
+    return dict(logmel=logmel, padding=padding, cost=cost, dtw=dtw, logprob=logprob)
+
+
+# stage -> lane: with --overlap the three lanes run on three HIP streams (the stages of one lane stay ordered)
+LANES = [["logmel", "padding"], ["cost", "dtw"], ["logprob"]]
+
+
+def run_step(w, ev=None, streams=None):
+    """One pass of the hot path.  ev: optional {stage: (start_event, end_event)}, recorded on the stream the stage's
+    kernels are launched on.  streams: None = everything on the current stream, in order; else 3 torch streams."""
+    calls = w.setdefault("_calls", _stage_calls(w))
+    main = torch.cuda.current_stream()
+    if streams is None:
+        for lane in LANES:
+            for stage in lane:
+                if ev: ev[stage][0].record(main)
+                calls[stage](main.cuda_stream)
+                if ev: ev[stage][1].record(main)
+    else:
+        fork = w.setdefault("_fork", torch.cuda.Event())
+        fork.record(main)
+        for lane, s in zip(LANES, streams):
+            s.wait_event(fork)
+            for stage in lane:
+                if ev: ev[stage][0].record(s)
+                calls[stage](s.cuda_stream)
+                if ev: ev[stage][1].record(s)
+            main.wait_stream(s)
     w["host_jumps"].copy_(w["jumps"], non_blocking=True)
     w["host_logprob"].copy_(w["logprob"], non_blocking=True)
 
@@ -154,6 +208,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the three independent lanes (log-mel | cost+DTW | log-prob) on three HIP streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,8 +233,10 @@ def main():
         from whisper_timestamped.sharding import ResultGatherer
         gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev)
 
+    streams = [torch.cuda.Stream(device=dev) for _ in LANES] if args.overlap else None
+
     def full_step(ev=None):
-        run_step(w, ev)
+        run_step(w, ev, streams)
         if gather_buf is not None:
             gather_buf.gather(w["jumps"], w["logprob"])
 
@@ -186,7 +244,8 @@ def main():
         full_step()
     torch.cuda.synchronize()
 
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    evs = [{st: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for st in STAGES}
+           for _ in range(args.steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -210,8 +269,8 @@ def main():
     assert np.isfinite(w["host_logprob"].numpy()).all()
 
     if rank == 0:
-        stage_ms = {s: float(np.mean([evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)]))
-                    for i, s in enumerate(STAGES)}
+        stage_ms = {s: float(np.mean([evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps)]))
+                    for s in STAGES}
         ab = algorithmic_bytes(cfg)
         dom = max(stage_ms, key=stage_ms.get)
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
@@ -219,6 +278,7 @@ def main():
                       "GBps": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1),
                       "frac_hbm": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for s in STAGES}
         ms_per_step = elapsed / args.steps * 1e3
+        traffic, traffic_src = committed_traffic(dom)
         out = {
             "metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks",
             "value": round(world * n * 30.0 * args.steps / elapsed, 1),
@@ -227,9 +287,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (cost, log-softmax, mel) / f64 (DTW)",
             "data": "synthetic",
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
+                       "streams": 3 if args.overlap else 1,
                        "result_gather": "rccl gather to rank 0" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],
+                         "achievable_peak_measured": 6290.0},
             "stages": stages,
         }
         if not args.no_cpu_baseline:

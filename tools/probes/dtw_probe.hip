@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <algorithm>
 namespace wt { void set_error(const char *, ...) {} int hip_fail(hipError_t e, const char *w) { printf("HIP fail %s\n", w); return -2; }
 int scratch(size_t, void **) { return 0; } }
 int main(int argc, char **argv) {
@@ -13,6 +14,19 @@ int main(int argc, char **argv) {
     for (int b = 0; b < n; ++b) { d[b] = {}; d[b].T = T; d[b].F = F; d[b].cost_offset = b * per; d[b].jumps_offset = b * (T + 1); d[b].pad_from = -1; }
     std::vector<float> c(n * per + 4);
     srand(1); for (auto &v : c) v = -(float)rand() / RAND_MAX;
+    if (argc > 3 && atoi(argv[3]) == 1) {  // bench-like cost: small noise + a deep ridge on a random monotone staircase
+        for (int b = 0; b < n; ++b) {
+            std::vector<int> st(T);
+            for (int t = 0; t < T; ++t) st[t] = rand() % F;
+            std::sort(st.begin(), st.end());
+            for (int t = 0; t < T; ++t)
+                for (int f = 0; f < F; ++f) {
+                    float v = -0.002f * ((float)rand() / RAND_MAX);
+                    if (abs(f - st[t]) <= 1) v -= 0.3f;
+                    c[b * per + (size_t)t * F + f] = v;
+                }
+        }
+    }
     float *dc; wt_seg_desc *dd; int32_t *dj;
     hipMalloc(&dc, c.size() * 4); hipMalloc(&dd, n * sizeof(wt_seg_desc)); hipMalloc(&dj, n * (T + 1) * 4);
     hipMemcpy(dc, c.data(), c.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dd, d.data(), n * sizeof(wt_seg_desc), hipMemcpyHostToDevice);

@@ -62,25 +62,37 @@ constexpr int MAX_MELS = 256;
 // Per-call preparation, ONE workgroup: reset the per-chunk max keys and turn the dense (n_mels x 201)
 // filterbank into its banded form: lo[m], n[m], off[m] and the concatenated non-zero spans.
 // ws layout (ints): keys[n_chunks] | lo[MAX_MELS] | n[MAX_MELS] | off[MAX_MELS] | total | weights[NNZ_CAP]
+constexpr int INIT_ROWS = 64;  // filterbank rows staged through LDS per trip (64 x 201 floats = 51 KB)
 __global__ __launch_bounds__(256) void logmel_init_kernel(int *ws, const float *__restrict__ fb, int n_chunks, int n_mels) {
-    __shared__ int s_lo[MAX_MELS], s_hi[MAX_MELS], s_off[MAX_MELS];
+    __shared__ float tile[INIT_ROWS * 201];
+    __shared__ int s_lo[MAX_MELS], s_w[MAX_MELS], s_off[MAX_MELS];
     const int tid = threadIdx.x;
     int *keys = ws, *lo = ws + n_chunks, *cnt = lo + MAX_MELS, *off = cnt + MAX_MELS, *total = off + MAX_MELS;
     float *wts = reinterpret_cast<float *>(total + 1);
     for (int t = tid; t < n_chunks; t += 256) keys[t] = (int)0x80000000;
-    s_lo[tid] = 201;
-    s_hi[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < n_mels * 201; e += 256) {
-        if (fb[e] != 0.f) {
-            const int m = e / 201, k = e - m * 201;
-            atomicMin(&s_lo[m], k);
-            atomicMax(&s_hi[m], k + 1);
+    s_lo[tid] = 0;
+    s_w[tid] = 0;
+    for (int m0 = 0; m0 < n_mels; m0 += INIT_ROWS) {
+        const int rows = min(INIT_ROWS, n_mels - m0);
+        __syncthreads();
+        for (int e = tid; e < rows * 201; e += 256) tile[e] = fb[m0 * 201 + e];  // coalesced
+        __syncthreads();
+        if (tid < rows) {  // one thread per filter: first / last non-zero tap (row stride 201 is odd: no bank conflicts)
+            const float *r = tile + tid * 201;
+            int first = 201, last = 0;
+            for (int k = 0; k < 201; ++k)
+                if (r[k] != 0.f) {
+                    first = min(first, k);
+                    last = k + 1;
+                }
+            if (first < last) {
+                s_lo[m0 + tid] = first;
+                s_w[m0 + tid] = last - first;
+            }
         }
     }
     __syncthreads();
-    const int width = (tid < n_mels && s_lo[tid] < s_hi[tid]) ? s_hi[tid] - s_lo[tid] : 0;
-    if (width == 0) s_lo[tid] = 0;
+    const int width = s_w[tid];
     s_off[tid] = width;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {  // inclusive Hillis-Steele scan
@@ -89,14 +101,18 @@ __global__ __launch_bounds__(256) void logmel_init_kernel(int *ws, const float *
         s_off[tid] += v;
         __syncthreads();
     }
-    const int my_off = s_off[tid] - width;
-    if (tid < n_mels) { lo[tid] = s_lo[tid]; cnt[tid] = width; off[tid] = my_off; }
     const int tot = s_off[255];
+    if (tid < n_mels) { lo[tid] = s_lo[tid]; cnt[tid] = width; off[tid] = s_off[tid] - width; }
     if (tid == 0) *total = tot;
     if (tot <= NNZ_CAP)
-        for (int m = 0; m < n_mels; ++m) {  // block-cooperative copy of each band
-            const int w = s_off[m] - (m ? s_off[m - 1] : 0), o = s_off[m] - w;
-            for (int k = tid; k < w; k += 256) wts[o + k] = fb[m * 201 + s_lo[m] + k];
+        for (int e = tid; e < tot; e += 256) {  // element e of the concatenated bands: find its filter (s_off inclusive)
+            int a = 0, b = n_mels - 1;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (s_off[mid] > e) b = mid; else a = mid + 1;
+            }
+            const int k = e - (s_off[a] - s_w[a]);
+            wts[e] = fb[a * 201 + s_lo[a] + k];
         }
 }
 
