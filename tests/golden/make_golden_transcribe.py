@@ -131,6 +131,9 @@ def case_list():
                   opts=dict(language="fr", refine_whisper_precision=0.0),
                   script=[window_script(ML, EOT_ML, [(5, [11771, 17134, 4666, 1022, 875, 2557, 68], 260),
                                                      (270, [6992, 631, 269, 6, 377, 409, 7282], 490)], "eot")]))
+    C.append(dict(name="vad_explicit_islands", model="tiny", audio_s=30.0, audio_seed=18,
+                  opts=dict(language="en", vad=[(2.0, 9.5), (14.0, 21.25)]),
+                  script=[window_script(ML, EOT_ML, [seg(33, 5, 8, 330), seg(34, 340, 9, 700)], "eot")]))
     # ---- naive strategy (transcribe, then teacher-forced re-run) -------------------------------------
     C.append(dict(name="naive_greedy", model="tiny", audio_s=12.0, audio_seed=14,
                   opts=dict(language="en", naive_approach=True),
@@ -164,6 +167,8 @@ def build_case(c, device="cpu"):
 def public_view(result):
     """What the parity test compares: the JSON surface (times, texts, confidences)."""
     out = dict(text=result["text"], language=result.get("language"), segments=[])
+    if "speech_activity" in result:
+        out["speech_activity"] = result["speech_activity"]
     if "language_probs" in result:
         lp = result["language_probs"]
         top = sorted(lp, key=lp.get, reverse=True)[:3]

@@ -38,6 +38,7 @@ def compare(got, exp, time_tol, conf_tol, logprob_tol=1e-4):
     assert got["text"] == exp["text"]
     assert got["language"] == exp["language"]
     assert len(got["segments"]) == len(exp["segments"])
+    assert got.get("speech_activity") == exp.get("speech_activity")
     if "language_probs_top" in exp:
         assert list(got["language_probs_top"]) == list(exp["language_probs_top"])
         for k, v in exp["language_probs_top"].items():

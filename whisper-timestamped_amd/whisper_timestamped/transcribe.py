@@ -15,7 +15,9 @@ import torch
 from . import backend as _backend
 from .efficient import transcribe_efficient
 from .naive import transcribe_naive
+from .naive import get_audio_tensor
 from .postprocess import ensure_increasing_positions, remove_last_null_duration_words
+from .vad import check_vad_method, remove_non_speech
 from .words import AUDIO_TIME_PER_TOKEN, HOP_LENGTH, N_FRAMES, SAMPLE_RATE
 
 logger = logging.getLogger("whisper_timestamped")
@@ -89,8 +91,8 @@ def print_timestamped(word):
 
 
 def load_model(name, device=None, backend="openai-whisper", download_root=None, in_memory=False):
-    """transcribe.py:2405-2544 for openai-whisper identifiers / ``.pt`` files.  HuggingFace checkpoint
-    conversion is a "next" row and is not built."""
+    """transcribe.py:2405-2544: openai-whisper identifiers / ``.pt`` files through whisper.load_model, anything
+    else is taken as a HuggingFace-format checkpoint and converted (checkpoint.py)."""
     import os
     if backend == "transformers":
         raise NotImplementedError("backend 'transformers': only openai-whisper models are supported on this path")
@@ -103,7 +105,8 @@ def load_model(name, device=None, backend="openai-whisper", download_root=None, 
             device = "cuda" if torch.cuda.is_available() else "cpu"
         return w.load_model(name, device=device, download_root=os.path.join(download_root, "whisper") if download_root else None,
                             in_memory=in_memory)
-    raise NotImplementedError(f"{name!r}: HuggingFace checkpoint conversion is not built (SURVEY.md 8(f) N4)")
+    from .checkpoint import convert_hf_state_dict, find_checkpoint_files, torch_load
+    return convert_hf_state_dict(torch_load(find_checkpoint_files(name, download_root)), device)
 
 
 def transcribe_timestamped(
@@ -168,9 +171,7 @@ def transcribe_timestamped(
     if is_transformer_model(model) or use_backend_timestamps:
         naive_approach = True
 
-    if vad not in (None, False):
-        raise NotImplementedError("vad: the VAD front ends (silero / auditok) are outside the accelerated path "
-                                  "(SURVEY.md 8(f) N3)")
+    vad = check_vad_method(vad)
     if isinstance(model, str):
         model = load_model(model)
     if fp16 is None:
@@ -196,10 +197,18 @@ def transcribe_timestamped(
     whisper_options = dict(
         language=language, task=task, fp16=fp16, temperature=temperature, best_of=best_of, beam_size=beam_size,
         patience=patience, length_penalty=length_penalty, condition_on_previous_text=condition_on_previous_text,
-        initial_prompt=initial_prompt, suppress_tokens=suppress_tokens, sample_len=sample_len, verbose=verbose,
+        initial_prompt=initial_prompt, suppress_tokens=suppress_tokens, sample_len=sample_len,
+        verbose=verbose if (not vad or verbose is not True) else False,
     )
     other_options = dict(no_speech_threshold=no_speech_threshold, logprob_threshold=logprob_threshold,
                          compression_ratio_threshold=compression_ratio_threshold)
+
+    if vad is not None:
+        audio = get_audio_tensor(audio)
+        audio, vad_segments, convert_timestamps = remove_non_speech(audio, method=vad, sample_rate=SAMPLE_RATE,
+                                                                    plot=plot_word_alignment, avoid_empty_speech=True)
+    else:
+        vad_segments = None
 
     if naive_approach:
         transcription, words = transcribe_naive(model, audio, min_word_duration=0.0,
@@ -216,7 +225,7 @@ def transcribe_timestamped(
 
     segments = transcription["segments"]
     for word in words:
-        if verbose and not naive_approach:
+        if verbose and not naive_approach and not vad:
             print_timestamped(word)
         word.pop("tokens", None)
         word.pop("tokens_indices", None)
@@ -232,6 +241,20 @@ def transcribe_timestamped(
                 segment["start"] = word["start"]
         if refine_whisper_precision:
             segment["end"] = word["end"]
+
+    if vad:                                                     # back to the time axis of the original audio
+        for segment in segments:
+            for word in segment.get("words", []):
+                word["start"], word["end"] = convert_timestamps(word["start"], word["end"])
+                if verbose:
+                    print_timestamped(word)
+            if refine_whisper_precision and len(segment.get("words", [])):
+                segment["start"] = segment["words"][0]["start"]
+                segment["end"] = segment["words"][-1]["end"]
+            else:
+                segment["start"], segment["end"] = convert_timestamps(segment["start"], segment["end"])
+    if vad_segments is not None:
+        transcription["speech_activity"] = [{"start": s, "end": e} for (s, e) in vad_segments]
     return transcription
 
 
