@@ -100,6 +100,8 @@ int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, co
  * dtw-python semantics (f64 accumulation; candidates diagonal, same-token/
  * previous-frame, previous-token/same-frame; strict '<', first wins; closed
  * ends), in-kernel backtrack.  Bit-exact integer outputs for a given cost.
+ *   cost     : device fp32; MUST stay readable for 16 bytes past the end of the last unit (the sweep prefetches
+ *              its cost rows with unconditional 16-byte loads; the extra floats are never used)
  *   jumps    : device int32, T+1 per unit at jumps_offset
  *   path_i/j : optional (may be NULL) device int32, warping path
  *              (alignment.index1s / index2s) at path_offset, forward order

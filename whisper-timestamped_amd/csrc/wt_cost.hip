@@ -22,7 +22,9 @@
 //   T*F*4 written.
 // Kernel 2 (colnorm): per 64-column tile, column sum of squares over tokens
 //   (f64 accumulate), in-place normalise/negate/mask, per-unit min via one
-//   atomicMax on the magnitude bits.  Kernel 3 (fix00): cost[0,0] = min.
+//   atomicMax on the magnitude bits; the unit's last tile to finish writes
+//   cost[0,0] = min (a per-unit arrival counter, zeroed by kernel 1: no memset,
+//   no third launch).
 #include <hip/hip_fp16.h>
 
 #include "wt_common.h"
@@ -64,7 +66,7 @@ __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float 
 template <int C, typename QT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                       const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                      float *__restrict__ cost) {
+                                                      float *__restrict__ cost, unsigned *__restrict__ segstate) {
     constexpr int CAP = C * 64;
     constexpr int FLO = (C - 4) * 64;
     constexpr int BUF = CAP + 8;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const int t = blockIdx.x * 4 + wave;
     if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
     const int nch = (F + 63) >> 6;
+    if (t == 0 && lane < 2) segstate[2 * blockIdx.y + lane] = 0u;  // per-unit {max bits, finished tiles} for colnorm
 
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     // halo duty of lanes 0..7: scipy 'reflect' source index of positions -4..-1 and F..F+3
@@ -171,7 +174,7 @@ constexpr int CN_WAVES = 16;
 constexpr int CN_ROWS = (WT_MAX_TOKENS + CN_WAVES - 1) / CN_WAVES;
 __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restrict__ cost,
                                                                 const wt_seg_desc *__restrict__ segs,
-                                                                unsigned *__restrict__ segmax) {
+                                                                unsigned *__restrict__ segstate) {
     const wt_seg_desc d = segs[blockIdx.y];
     const int F = d.F, T = d.T;
     if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
         snorm[lane] = norm;
         float r = valid ? m / norm : 0.f;  // max_t(w/norm) == max_t(w)/norm: IEEE division is monotone
         r = wave_max(r);
-        if (lane == 0) atomicMax(segmax + blockIdx.y, __float_as_uint(r));
+        if (lane == 0) atomicMax(segstate + 2 * blockIdx.y, __float_as_uint(r));
     }
     __syncthreads();
     const float norm = snorm[lane];
@@ -221,20 +224,27 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
 #pragma unroll
         for (int r = 0; r < CN_ROWS; ++r) {
             const int t = wave + r * CN_WAVES;
-            if (t < T) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
+            // cost[0,0] is written once, by the unit's last tile (below): two tiles on different XCDs must not
+            // both hold that word dirty in their (mutually non-coherent) L2s
+            if (t < T && (t | f) != 0) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
+        }
+    }
+    // transcribe.py:1568  cost[0,0] = cost.min(): the tile that finishes last knows the unit's maximum magnitude
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned ntiles = (unsigned)((F + 63) >> 6);
+        if (atomicAdd(segstate + 2 * blockIdx.y + 1, 1u) == ntiles - 1) {
+            const unsigned bits = __hip_atomic_load(segstate + 2 * blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cost[d.cost_offset] = -__uint_as_float(bits);
         }
     }
 }
 
-__global__ void fix00_kernel(float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, const unsigned *__restrict__ segmax,
-                             int n_seg) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n_seg) cost[segs[s].cost_offset] = -__uint_as_float(segmax[s]);
-}
-
 template <typename QT>
 static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
-                          const int32_t *head_idx, int n_heads, float qk_scale, float *cost, hipStream_t st) {
+                          const int32_t *head_idx, int n_heads, float qk_scale, float *cost, unsigned *segstate,
+                          hipStream_t st) {
     int maxT[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < n_seg; ++i) {
         const int c = (segs_host[i].F + 255) / 256 - 1;  // C = 4*(c+1)
@@ -244,7 +254,7 @@ static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_host, const wt_s
     if (maxT[CI] > 0) {                                                                                             \
         dim3 grid((maxT[CI] + 3) / 4, n_seg);                                                                       \
         hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx,      \
-                           n_heads, qk_scale, cost);                                                                \
+                           n_heads, qk_scale, cost, segstate);                                                      \
     }
     WT_LAUNCH_ROWMEAN(0)
     WT_LAUNCH_ROWMEAN(1)
@@ -278,21 +288,19 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
         }
         if (d.F > maxF) maxF = d.F;
     }
-    unsigned *segmax = nullptr;
-    int rc = scratch((size_t)n_seg * sizeof(unsigned), (void **)&segmax);
+    unsigned *segstate = nullptr;  // per unit {max |cost| bits, finished colnorm tiles}: zeroed by rowmean
+    int rc = scratch((size_t)n_seg * 2 * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
-    WT_HIP(hipMemsetAsync(segmax, 0, (size_t)n_seg * sizeof(unsigned), st));
     if (qk_dtype == WT_DTYPE_F32)
-        rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, st);
+        rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);
     else if (qk_dtype == WT_DTYPE_F16)
-        rc = launch_rowmean((const __half *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, st);
+        rc = launch_rowmean((const __half *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);
     else {
         set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
         return WT_E_BADARG;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segmax);
-    hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segmax, n_seg);
+    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

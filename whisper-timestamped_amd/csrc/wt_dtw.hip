@@ -25,6 +25,8 @@
 // its own cost row with a 32-frame register prefetch.  Algorithmic HBM bytes:
 // T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its F+T-cell
 // dependency chain; throughput comes from the batch.
+#include <mutex>
+
 #include "wt_common.h"
 
 namespace wt {
@@ -45,7 +47,7 @@ __device__ long long wt_probe_clk[16];
 // s_waitcnt (with a divergent slow path it fell back to vmcnt(0) at the first use of the previous block,
 // i.e. the whole memory latency was exposed once per block: measured 3x on the kernel).  Frames outside
 // [0,F) read neighbouring (finite) entries of the same unit -- those cells never feed a valid cell -- and
-// the flat index is clamped into the unit; the last row may read up to 12 bytes past T*F (documented slack).
+// the flat index is clamped into the unit; the last row may read up to 12 bytes past T*F (the read slack include/wtalign.h asks for).
 __device__ __forceinline__ void load_blk(const float *__restrict__ unit, int flat, int last, float (&dst)[BLK]) {
 #pragma unroll
     for (int k = 0; k < BLK / 4; ++k) {
@@ -276,12 +278,13 @@ size_t dtw_lds_bytes(int nw, int F) {
 template <bool DIST, bool TINY>
 static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static std::once_flag once;  // per instantiation; function attributes are per process on one device
+    hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [&] {
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    WT_HIP(attr_rc);
     for (int nw = 1; nw <= 4; ++nw) {
         if (maxF[nw] == 0) continue;
         const size_t lds = dtw_lds_bytes(nw, maxF[nw]);

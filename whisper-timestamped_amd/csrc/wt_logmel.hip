@@ -19,6 +19,7 @@
 // clamp/scale and the zero padding.  Algorithmic bytes: 480000*4 read +
 // n_mels*3000*4 written per chunk (the intermediate is re-read from L2).
 #include <cmath>
+#include <mutex>
 
 #include "wt_common.h"
 
@@ -306,8 +307,10 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
 
 int scratch2(size_t bytes, void **out);
 
+static std::mutex g_tables_mu;
 static int upload_tables(hipStream_t st) {
     static bool done = false;
+    std::lock_guard<std::mutex> lk(g_tables_mu);
     static float hann[400];
     static float2 w400[400];
     if (done) return WT_OK;

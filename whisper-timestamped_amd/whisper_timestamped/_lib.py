@@ -97,14 +97,15 @@ def descs_to_device(descs: np.ndarray, device) -> torch.Tensor:
 
 
 def layout_outputs(descs: np.ndarray):
-    """Fill cost/jumps/path offsets (cost slots 16-byte aligned). Returns totals."""
+    """Fill cost/jumps/path offsets (cost slots 16-byte aligned).  Returns totals; the cost total includes the
+    16 bytes of read slack wt_dtw_batch asks for (include/wtalign.h)."""
     c = j = p = 0
     for d in descs:
         d["cost_offset"], d["jumps_offset"], d["path_offset"] = c, j, p
         c += (int(d["T"]) * int(d["F"]) + 3) & ~3
         j += int(d["T"]) + 1
         p += int(d["T"]) + int(d["F"]) - 1
-    return c, j, p
+    return c + 4, j, p
 
 
 def cost_batch(qk: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, head_idx: torch.Tensor, cost: torch.Tensor,
