@@ -83,7 +83,9 @@ def case_list():
     EOT_ML, EOT_EN = 50257, 50256
 
     def seg(seed, s, n, e):
-        return (s, text_ids(seed, n), e)
+        """n text tokens between <|s|> and <|e|>: odd seeds script the ids (low probability under a random model),
+        even seeds let the model pick its most likely text token (None) so that confidences are not all ~0."""
+        return (s, text_ids(seed, n) if seed % 2 else [None] * n, e)
 
     C.append(dict(name="one_window_two_segments", model="tiny", audio_s=12.0, audio_seed=1,
                   opts=dict(language="en"),
@@ -140,8 +142,9 @@ def case_list():
                   script=[window_script(ML, EOT_ML, [seg(26, 10, 7, 200), seg(27, 210, 8, 560)], "eot")]))
     C.append(dict(name="naive_beam", model="tiny", audio_s=41.0, audio_seed=15,
                   opts=dict(language="en", beam_size=2),
-                  script=[window_script(ML, EOT_ML, [seg(28, 0, 6, 400), seg(29, 420, 7, 1100)], "pair"),
-                          window_script(ML, EOT_ML, [seg(30, 12, 6, 380)], "eot")]))
+                  # (beam search is forced at the RESULT level: explicit ids only, i.e. odd seeds)
+                  script=[window_script(ML, EOT_ML, [seg(41, 0, 6, 400), seg(29, 420, 7, 1100)], "pair"),
+                          window_script(ML, EOT_ML, [seg(43, 12, 6, 380)], "eot")]))
     C.append(dict(name="naive_no_trust", model="tiny", audio_s=13.0, audio_seed=16,
                   opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False,
                             include_punctuation_in_confidence=True),

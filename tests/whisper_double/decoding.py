@@ -35,10 +35,12 @@ class Script:
         self._i = 0
         self.record.append([])
 
-    def pick(self, natural: int) -> int:
+    def pick(self, natural: int, logits_row=None, eot=None) -> int:
         tok = natural
         if self.windows is not None and self._k < len(self.windows) and self._i < len(self.windows[self._k]):
             tok = self.windows[self._k][self._i]
+            if tok is None:       # "the most likely TEXT token": keeps the scripted structure, meaningful probabilities
+                tok = int(logits_row[:eot].argmax())
         self._i += 1
         self.record[-1].append(int(tok))
         return int(tok)
@@ -176,7 +178,8 @@ class GreedyDecoder:
         else:
             next_tokens = Categorical(logits=logits / self.temperature).sample()
         if _SCRIPT is not None:
-            next_tokens = torch.tensor([_SCRIPT.pick(int(t)) for t in next_tokens.tolist()], device=logits.device)
+            next_tokens = torch.tensor([_SCRIPT.pick(int(t), logits[k], self.eot) for k, t in enumerate(next_tokens.tolist())],
+                                       device=logits.device)
         logprobs = F.log_softmax(logits.float(), dim=-1)
         current = logprobs[torch.arange(logprobs.shape[0]), next_tokens]
         sum_logprobs += current * (tokens[:, -1] != self.eot)

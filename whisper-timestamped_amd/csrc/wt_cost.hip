@@ -216,7 +216,23 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
         snorm[lane] = norm;
         float r = valid ? m / norm : 0.f;  // max_t(w/norm) == max_t(w)/norm: IEEE division is monotone
         r = wave_max(r);
-        if (lane == 0) atomicMax(segstate + 2 * blockIdx.y, __float_as_uint(r));
+        if (lane == 0) {
+            // one 64-bit word per unit: {tiles finished : max |cost| bits}.  A single CAS both merges this tile's
+            // maximum and counts it, so the tile that completes the count holds the unit's final maximum without
+            // any fence (an agent-scope release would write the whole L2 back: measured +30% on this stage).
+            unsigned long long *state = reinterpret_cast<unsigned long long *>(segstate) + blockIdx.y;
+            const unsigned ntiles = (unsigned)((F + 63) >> 6);
+            unsigned long long seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+            unsigned mx, cnt;
+            do {
+                mx = max((unsigned)seen, __float_as_uint(r));
+                cnt = (unsigned)(seen >> 32) + 1u;
+                want = ((unsigned long long)cnt << 32) | mx;
+            } while (!__hip_atomic_compare_exchange_strong(state, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+            // transcribe.py:1568  cost[0,0] = cost.min()
+            if (cnt == ntiles) cost[d.cost_offset] = -__uint_as_float(mx);
+        }
     }
     __syncthreads();
     const float norm = snorm[lane];
@@ -224,19 +240,9 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
 #pragma unroll
         for (int r = 0; r < CN_ROWS; ++r) {
             const int t = wave + r * CN_WAVES;
-            // cost[0,0] is written once, by the unit's last tile (below): two tiles on different XCDs must not
+            // cost[0,0] is written once, by the unit's last tile (above): two tiles on different XCDs must not
             // both hold that word dirty in their (mutually non-coherent) L2s
             if (t < T && (t | f) != 0) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
-        }
-    }
-    // transcribe.py:1568  cost[0,0] = cost.min(): the tile that finishes last knows the unit's maximum magnitude
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned ntiles = (unsigned)((F + 63) >> 6);
-        if (atomicAdd(segstate + 2 * blockIdx.y + 1, 1u) == ntiles - 1) {
-            const unsigned bits = __hip_atomic_load(segstate + 2 * blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cost[d.cost_offset] = -__uint_as_float(bits);
         }
     }
 }

@@ -31,12 +31,16 @@ from .words import HOP_LENGTH, N_AUDIO_CTX, SAMPLE_RATE
 
 logger = logging.getLogger("whisper_timestamped")
 
+# storage type of the captured cross-attention rows: float32 = what the reference sees (qk.float());
+# float16 halves the HBM bytes of the cost kernel (build-side option, BASELINE config 5; parity quantified in tests)
+RING_DTYPE = torch.float32
+
 
 class EfficientSession:
     def __init__(self, model, whisper_options, *, remove_punctuation_from_words, compute_word_confidence,
                  include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
                  word_alignment_most_top_layers, detect_disfluencies, trust_whisper_timestamps,
-                 use_timestamps_for_alignment=True, ring_dtype=torch.float32):
+                 use_timestamps_for_alignment=True, ring_dtype=None):
         self.model = model
         self.opts = whisper_options
         self.remove_punctuation_from_words = remove_punctuation_from_words
@@ -64,7 +68,7 @@ class EfficientSession:
         dev = model.device
         _lib.require_gpu(dev)
         self.ring = QKCaptureRing(dev, head_pairs(alignment_heads), len(self.hooked_blocks), model.dims.n_text_head,
-                                  n_ctx=model.dims.n_audio_ctx, capacity=self.n_ctx, dtype=ring_dtype)
+                                  n_ctx=model.dims.n_audio_ctx, capacity=self.n_ctx, dtype=ring_dtype or RING_DTYPE)
         self.logits = LogitsRing(dev, model.dims.n_vocab, capacity=self.n_ctx + 1)
         self.embedding_t = None
 
