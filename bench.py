@@ -252,6 +252,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         full_step(evs[k])
+    if gather_buf is not None:
+        gather_buf.drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -284,9 +286,10 @@ def main():
             "value": round(world * n * 30.0 * args.steps / elapsed, 1),
             "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (cost, log-softmax, mel) / f64 (DTW)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
+                       "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "streams": 3 if args.overlap else 1,
                        "result_gather": "rccl gather to rank 0" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -295,7 +298,7 @@ def main():
                          "achievable_peak_measured": 6290.0},
             "stages": stages,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, w)
         print(json.dumps(out))
     if dist is not None:

@@ -78,7 +78,8 @@ def _worker(rank, world, port, out_path):
             oj += T + 1
             ol += T
         g = ResultGatherer(dist, cap_j, cap_l, "cpu")
-        g.gather(jumps, lps)
+        for step in range(3):                     # the double-buffered async path: earlier steps carry other payloads
+            g.gather(jumps if step == 2 else jumps + step + 1, lps)
         if rank == 0:
             got = {}
             for r in range(world):

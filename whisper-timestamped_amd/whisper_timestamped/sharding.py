@@ -51,23 +51,45 @@ def broadcast_module_weights(dist, module: torch.nn.Module, src: int = 0):
 
 
 class ResultGatherer:
-    """Fixed-size gather of per-rank result records to rank 0 (preallocated
-    buffers: nothing is allocated per step)."""
+    """Fixed-size gather of per-rank result records to rank 0.
 
-    def __init__(self, dist, n_jumps: int, n_logprob: int, device):
+    Buffers are preallocated (nothing is allocated per step) and DOUBLE-BUFFERED: ``gather`` launches the
+    collective asynchronously and returns; the collective of step k overlaps the kernels of step k+1, and a
+    buffer is only rewritten after the collective that read it has been waited for (stream-side wait on the GPU,
+    no host sync).  ``latest()`` waits for the newest collective and returns its receive list (rank 0)."""
+
+    def __init__(self, dist, n_jumps: int, n_logprob: int, device, depth: int = 2):
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.n_jumps, self.n_logprob = n_jumps, n_logprob
         # one int32 record: jumps followed by the log-probs' bit patterns
-        self.send = torch.empty(n_jumps + n_logprob, dtype=torch.int32, device=device)
-        self.recv = ([torch.empty_like(self.send) for _ in range(self.world)] if self.rank == 0 else None)
+        self.send = [torch.empty(n_jumps + n_logprob, dtype=torch.int32, device=device) for _ in range(depth)]
+        self.recv = [([torch.empty_like(self.send[0]) for _ in range(self.world)] if self.rank == 0 else None)
+                     for _ in range(depth)]
+        self.work = [None] * depth
+        self.k = -1
 
     def gather(self, jumps: torch.Tensor, logprob: torch.Tensor):
-        self.send[: self.n_jumps].copy_(jumps)
-        self.send[self.n_jumps:].copy_(logprob.view(torch.int32))
-        self.dist.gather(self.send, self.recv, dst=0)
-        return self.recv
+        self.k = (self.k + 1) % len(self.send)
+        k = self.k
+        if self.work[k] is not None:
+            self.work[k].wait()              # the collective that last used this buffer pair
+        send = self.send[k]
+        send[: self.n_jumps].copy_(jumps)
+        send[self.n_jumps:].copy_(logprob.view(torch.int32))
+        self.work[k] = self.dist.gather(send, self.recv[k], dst=0, async_op=True)
+        return self.work[k]
+
+    def latest(self):
+        if self.k >= 0 and self.work[self.k] is not None:
+            self.work[self.k].wait()
+        return self.recv[self.k]
+
+    def drain(self):
+        for w in self.work:
+            if w is not None:
+                w.wait()
 
     def unpack(self, r: int):
-        buf = self.recv[r]
+        buf = self.latest()[r]
         return buf[: self.n_jumps], buf[self.n_jumps:].view(torch.float32)
