@@ -22,9 +22,8 @@
 //   T*F*4 written.
 // Kernel 2 (colnorm): per 64-column tile, column sum of squares over tokens
 //   (f64 accumulate), in-place normalise/negate/mask, per-unit min via one
-//   atomicMax on the magnitude bits; the unit's last tile to finish writes
-//   cost[0,0] = min (a per-unit arrival counter, zeroed by kernel 1: no memset,
-//   no third launch).
+//   atomicMax on the magnitude bits (the word is zeroed by kernel 1: no memset
+//   node).  Kernel 3 (fix00): cost[0,0] = min.
 #include <hip/hip_fp16.h>
 
 #include "wt_common.h"
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const int t = blockIdx.x * 4 + wave;
     if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
     const int nch = (F + 63) >> 6;
-    if (t == 0 && lane < 2) segstate[2 * blockIdx.y + lane] = 0u;  // per-unit {max bits, finished tiles} for colnorm
+    if (t == 0 && lane == 0) segstate[blockIdx.y] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
 
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     // halo duty of lanes 0..7: scipy 'reflect' source index of positions -4..-1 and F..F+3
@@ -174,7 +173,7 @@ constexpr int CN_WAVES = 16;
 constexpr int CN_ROWS = (WT_MAX_TOKENS + CN_WAVES - 1) / CN_WAVES;
 __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restrict__ cost,
                                                                 const wt_seg_desc *__restrict__ segs,
-                                                                unsigned *__restrict__ segstate) {
+                                                                unsigned *__restrict__ segmax) {
     const wt_seg_desc d = segs[blockIdx.y];
     const int F = d.F, T = d.T;
     if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
@@ -216,23 +215,10 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
         snorm[lane] = norm;
         float r = valid ? m / norm : 0.f;  // max_t(w/norm) == max_t(w)/norm: IEEE division is monotone
         r = wave_max(r);
-        if (lane == 0) {
-            // one 64-bit word per unit: {tiles finished : max |cost| bits}.  A single CAS both merges this tile's
-            // maximum and counts it, so the tile that completes the count holds the unit's final maximum without
-            // any fence (an agent-scope release would write the whole L2 back: measured +30% on this stage).
-            unsigned long long *state = reinterpret_cast<unsigned long long *>(segstate) + blockIdx.y;
-            const unsigned ntiles = (unsigned)((F + 63) >> 6);
-            unsigned long long seen = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-            unsigned mx, cnt;
-            do {
-                mx = max((unsigned)seen, __float_as_uint(r));
-                cnt = (unsigned)(seen >> 32) + 1u;
-                want = ((unsigned long long)cnt << 32) | mx;
-            } while (!__hip_atomic_compare_exchange_strong(state, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-            // transcribe.py:1568  cost[0,0] = cost.min()
-            if (cnt == ntiles) cost[d.cost_offset] = -__uint_as_float(mx);
-        }
+        // fire-and-forget (no return value, nobody waits for it).  Folding cost[0,0] = min into this kernel was
+        // measured and dropped: a last-tile-done protocol needs either a release fence (writes the L2 back: +30 %
+        // on the stage) or a returning CAS on the critical path (colnorm 25 -> 68 us); a 4 us kernel is cheaper.
+        if (lane == 0) atomicMax(segmax + blockIdx.y, __float_as_uint(r));
     }
     __syncthreads();
     const float norm = snorm[lane];
@@ -240,11 +226,16 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
 #pragma unroll
         for (int r = 0; r < CN_ROWS; ++r) {
             const int t = wave + r * CN_WAVES;
-            // cost[0,0] is written once, by the unit's last tile (above): two tiles on different XCDs must not
-            // both hold that word dirty in their (mutually non-coherent) L2s
-            if (t < T && (t | f) != 0) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
+            if (t < T) base[(int64_t)t * F] = (masked_col && t < T - 1) ? 0.f : -(v[r] / norm);
         }
     }
+}
+
+// transcribe.py:1568  cost[0,0] = cost.min()
+__global__ void fix00_kernel(float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, const unsigned *__restrict__ segmax,
+                             int n_seg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_seg) cost[segs[s].cost_offset] = -__uint_as_float(segmax[s]);
 }
 
 template <typename QT>
@@ -294,8 +285,8 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
         }
         if (d.F > maxF) maxF = d.F;
     }
-    unsigned *segstate = nullptr;  // per unit {max |cost| bits, finished colnorm tiles}: zeroed by rowmean
-    int rc = scratch((size_t)n_seg * 2 * sizeof(unsigned), (void **)&segstate);
+    unsigned *segstate = nullptr;  // per unit max |cost| bits: zeroed by rowmean, merged by colnorm, used by fix00
+    int rc = scratch((size_t)n_seg * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);
@@ -307,6 +298,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     }
     if (rc) return rc;
     hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate);
+    hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segstate, n_seg);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
