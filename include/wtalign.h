@@ -134,6 +134,8 @@ int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_st
  * PCM chunks: hann-400 STFT (centre, reflect pad), hop 160, |.|^2, mel
  * (mel_fb: device fp32 [n_mels][201]), log10(max(.,1e-10)), max(x, max-8),
  * (x+4)/4; columns >= n_valid_frames[b] are exact zeros (pad_or_trim).
+ *   mel_fb         : its banded form is cached per (stream, pointer, n_mels): do not modify the weights in place
+ *                    while passing the same pointer (wt_shutdown() drops the cache)
  *   pcm            : device fp32 [n_chunks][n_samples]
  *   n_valid_samples: device int32[n_chunks] real samples per chunk (<= n_samples)
  *   mel_out        : device fp32 [n_chunks][n_mels][n_frames]

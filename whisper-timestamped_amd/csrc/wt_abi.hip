@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "wt_common.h"
@@ -26,17 +27,21 @@ int hip_fail(hipError_t e, const char *what) {
 struct Arena {
     void *p = nullptr;
     size_t cap = 0;
+    const void *tag_ptr = nullptr;  // what the owner last prepared in this arena (e.g. which filterbank)
+    long long tag_val = 0;
 };
 static std::mutex g_mu;
-static std::map<std::pair<int, int>, Arena> g_arena;  // per (device, purpose)
+// One arena per (device, purpose, stream): calls on distinct streams never share scratch (they may run concurrently),
+// calls on one stream are ordered by the stream.
+static std::map<std::tuple<int, int, hipStream_t>, Arena> g_arena;
 
-// Growing is a hipMalloc (synchronising, not graph-capturable); the first call
-// reserves enough for 64K units so that steady state never grows.
-static int scratch_ex(int purpose, size_t bytes, void **out) {
+// Growing is a hipMalloc (synchronising, not graph-capturable); the first call reserves at least 256 KB so that
+// steady state never grows.  `fresh` (optional) tells the caller that the memory is new (tags were reset).
+static int scratch_ex(int purpose, hipStream_t st, size_t bytes, void **out, Arena **arena) {
     int dev = 0;
     WT_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    Arena &a = g_arena[std::make_pair(dev, purpose)];
+    Arena &a = g_arena[std::make_tuple(dev, purpose, st)];
     if (bytes > a.cap) {
         size_t want = bytes < (256u << 10) ? (256u << 10) : bytes * 2;
         void *np = nullptr;
@@ -47,12 +52,29 @@ static int scratch_ex(int purpose, size_t bytes, void **out) {
         }
         a.p = np;
         a.cap = want;
+        a.tag_ptr = nullptr;
+        a.tag_val = 0;
     }
     *out = a.p;
+    if (arena) *arena = &a;
     return WT_OK;
 }
-int scratch(size_t bytes, void **out) { return scratch_ex(0, bytes, out); }   // cost path
-int scratch2(size_t bytes, void **out) { return scratch_ex(1, bytes, out); }  // log-mel path
+int scratch(hipStream_t st, size_t bytes, void **out) { return scratch_ex(0, st, bytes, out, nullptr); }  // cost path
+// log-mel path: returns true in *prepared when the arena already holds the preparation tagged (ptr, val)
+int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared) {
+    Arena *a = nullptr;
+    int rc = scratch_ex(1, st, bytes, out, &a);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(g_mu);
+    *prepared = (a->tag_ptr == tag_ptr && a->tag_val == tag_val && tag_ptr != nullptr);
+    a->tag_ptr = tag_ptr;
+    a->tag_val = tag_val;
+    return WT_OK;
+}
+void scratch_forget_tags() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_arena) kv.second.tag_ptr = nullptr;
+}
 
 int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, int, float, float *,
                hipStream_t);
@@ -78,7 +100,7 @@ int wt_shutdown(void) {
         if (kv.second.p) {
             int cur = 0;
             (void)hipGetDevice(&cur);
-            (void)hipSetDevice(kv.first.first);
+            (void)hipSetDevice(std::get<0>(kv.first));
             (void)hipFree(kv.second.p);
             (void)hipSetDevice(cur);
         }

@@ -18,8 +18,8 @@ int hip_fail(hipError_t e, const char *what);
         if (_e != hipSuccess) return ::wt::hip_fail(_e, #call); \
     } while (0)
 
-// per-device scratch arena: `bytes` of device memory, grown on demand
-int scratch(size_t bytes, void **out);
+// scratch arena of (current device, stream): `bytes` of device memory, grown on demand
+int scratch(hipStream_t st, size_t bytes, void **out);
 
 // ---- wave-level primitives (device) ---------------------------------------
 // Cross-lane LDS hand-off inside ONE wave: DS ops of a wave execute in issue

@@ -286,7 +286,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
         if (d.F > maxF) maxF = d.F;
     }
     unsigned *segstate = nullptr;  // per unit max |cost| bits: zeroed by rowmean, merged by colnorm, used by fix00
-    int rc = scratch((size_t)n_seg * sizeof(unsigned), (void **)&segstate);
+    int rc = scratch(st, (size_t)n_seg * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);

@@ -60,20 +60,18 @@ __device__ __forceinline__ float dec_key(int k) { return __int_as_float(k >= 0 ?
 constexpr int NNZ_CAP = 768;        // compact (banded) filterbank weights kept in LDS
 constexpr int MAX_MELS = 256;
 
-// ws layout (ints): keys[n_chunks] | lo[MAX_MELS] | n[MAX_MELS] | off[MAX_MELS] | total | weights[NNZ_CAP]
-// Per-call preparation, ONE workgroup of 16 waves: reset the per-chunk max keys and turn the dense (n_mels x 201)
-// filterbank into its banded form.  A wave owns rows w, w+16, ...: all of its rows are fetched with coalesced loads
+// ws layout (ints): lo[MAX_MELS] | n[MAX_MELS] | off[MAX_MELS] | total | weights[NNZ_CAP] | wgmax[n_chunks][n_wg] (float)
+// Preparation, ONE workgroup of 16 waves, run only when the arena does not already hold the banded form of this
+// filterbank (the result is cached per stream and (mel_fb pointer, n_mels)): dense (n_mels x 201) -> banded form.  A wave owns rows w, w+16, ...: all of its rows are fetched with coalesced loads
 // issued back to back (one memory latency), first / last non-zero tap by wave reductions, 256-entry prefix sum in
 // LDS, then the non-zero spans are copied.  ~4 us (a single-thread-per-row version took 48 us, an LDS-staged one 20).
 constexpr int INIT_WAVES = 16;
 constexpr int INIT_ROWS = MAX_MELS / INIT_WAVES;
-__global__ __launch_bounds__(64 * INIT_WAVES) void logmel_init_kernel(int *ws, const float *__restrict__ fb, int n_chunks,
-                                                                      int n_mels) {
+__global__ __launch_bounds__(64 * INIT_WAVES) void logmel_init_kernel(int *ws, const float *__restrict__ fb, int n_mels) {
     __shared__ int s_lo[MAX_MELS], s_w[MAX_MELS], s_off[MAX_MELS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int *keys = ws, *lo = ws + n_chunks, *cnt = lo + MAX_MELS, *off = cnt + MAX_MELS, *total = off + MAX_MELS;
+    int *lo = ws, *cnt = lo + MAX_MELS, *off = cnt + MAX_MELS, *total = off + MAX_MELS;
     float *wts = reinterpret_cast<float *>(total + 1);
-    for (int t = tid; t < n_chunks; t += 64 * INIT_WAVES) keys[t] = (int)0x80000000;
     float v[INIT_ROWS][4];
 #pragma unroll
     for (int r = 0; r < INIT_ROWS; ++r) {
@@ -128,8 +126,9 @@ __global__ __launch_bounds__(64 * INIT_WAVES) void logmel_init_kernel(int *ws, c
 
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__ pcm, int64_t n_samples,
                                                        const int32_t *__restrict__ n_valid_samples,
-                                                       const float *__restrict__ fb, const int *__restrict__ ws, int n_chunks,
-                                                       int n_mels, int n_frames, float *__restrict__ mel_out) {
+                                                       const float *__restrict__ fb, const int *__restrict__ ws,
+                                                       float *__restrict__ wgmax, int n_mels, int n_frames,
+                                                       float *__restrict__ mel_out) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
     static_assert(FPB * 204 >= SPAN, "the span must fit in the pw buffer");
@@ -139,14 +138,17 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     __shared__ float fbw[NNZ_CAP];
     __shared__ unsigned char fb_lo[MAX_MELS], fb_n[MAX_MELS];
     __shared__ unsigned short fb_off[MAX_MELS];
-    __shared__ int smax[4];
+    __shared__ float smax[4];
     float (*pw)[204] = reinterpret_cast<float (*)[204]>(span);
 
     const int chunk = blockIdx.y;
     const int f0 = blockIdx.x * FPB;
     const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
     const int nvf = min(nvs / 160, n_frames);  // frames kept after dropping the last stft frame
-    if (f0 >= nvf) return;                    // whole tile is padding (block-uniform)
+    if (f0 >= nvf) {                          // whole tile is padding (block-uniform)
+        if (threadIdx.x == 0) wgmax[(size_t)chunk * gridDim.x + blockIdx.x] = -INFINITY;
+        return;
+    }
     const float *x = pcm + (int64_t)chunk * n_samples;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     const bool act = lane < 60 && (f0 + slot) < nvf;
 
     // ---- phase A: every global read of the tile is issued here, one latency for all of them ----
-    const int *g_lo = ws + n_chunks, *g_n = g_lo + MAX_MELS, *g_off = g_n + MAX_MELS, *g_tot = g_off + MAX_MELS;
+    const int *g_lo = ws, *g_n = g_lo + MAX_MELS, *g_off = g_n + MAX_MELS, *g_tot = g_off + MAX_MELS;
     const float *g_w = reinterpret_cast<const float *>(g_tot + 1);
     const int nnz = *g_tot;
     const bool banded = nnz <= NNZ_CAP;
@@ -290,18 +292,25 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         lmax = fmaxf(lmax, v);
     }
     lmax = wave_max(lmax);
-    if (lane == 0) smax[wave] = enc_key(lmax);
+    if (lane == 0) smax[wave] = lmax;
     __syncthreads();
-    if (tid == 0) atomicMax(const_cast<int *>(ws) + chunk, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    // per-workgroup maximum, one slot per workgroup: no atomics, nothing to reset between calls
+    if (tid == 0) wgmax[(size_t)chunk * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
 }
 
-__global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const int *__restrict__ keys,
+__global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const float *__restrict__ wgmax, int n_wg,
                                                               const int32_t *__restrict__ n_valid_samples, int64_t n_samples,
                                                               int n_mels, int n_frames, float *__restrict__ gmax) {
     const int chunk = blockIdx.y;
     const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
     const int nvf = min(nvs / 160, n_frames);
-    const float mx = dec_key(keys[chunk]);
+    __shared__ float s_mx[4];
+    float m = -INFINITY;                      // the chunk's max of log10(mel): n_wg L2-resident floats per block
+    for (int g = threadIdx.x; g < n_wg; g += 256) m = fmaxf(m, wgmax[(size_t)chunk * n_wg + g]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
     const float floor_v = mx - 8.0f;
     float *base = mel_out + (int64_t)chunk * n_mels * n_frames;
     const int total = n_mels * n_frames;
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
     if (gmax && blockIdx.x == 0 && threadIdx.x == 0) gmax[chunk] = mx;
 }
 
-int scratch2(size_t bytes, void **out);
+int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared);
 
 static std::mutex g_tables_mu;
 static int upload_tables(hipStream_t st) {
@@ -344,17 +353,22 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     if (n_chunks == 0) return WT_OK;
     int rc = upload_tables(st);
     if (rc) return rc;
+    const int n_wg = (n_frames + FPB - 1) / FPB;
+    const size_t head_ints = 3 * MAX_MELS + 1 + NNZ_CAP;
     int *ws = nullptr;
-    rc = scratch2(((size_t)n_chunks + 3 * MAX_MELS + 1 + NNZ_CAP) * sizeof(int), (void **)&ws);
+    bool prepared = false;
+    rc = scratch_tagged(st, (head_ints + (size_t)n_chunks * n_wg) * sizeof(int), (void **)&ws, mel_fb, n_mels, &prepared);
     if (rc) return rc;
-    int *keys = ws;
-    hipLaunchKernelGGL(logmel_init_kernel, dim3(1), dim3(64 * INIT_WAVES), 0, st, ws, mel_fb, n_chunks, n_mels);
-    hipLaunchKernelGGL(stft_mel_kernel, dim3((n_frames + FPB - 1) / FPB, n_chunks), dim3(256), 0, st, pcm, n_samples,
-                       n_valid_samples, mel_fb, ws, n_chunks, n_mels, n_frames, mel_out);
+    float *wgmax = reinterpret_cast<float *>(ws + head_ints);
+    // The banded filterbank is cached in the stream's arena: the contents behind `mel_fb` must not change while the
+    // same pointer keeps being passed (wt_shutdown() or a different pointer / n_mels rebuilds it).
+    if (!prepared) hipLaunchKernelGGL(logmel_init_kernel, dim3(1), dim3(64 * INIT_WAVES), 0, st, ws, mel_fb, n_mels);
+    hipLaunchKernelGGL(stft_mel_kernel, dim3(n_wg, n_chunks), dim3(256), 0, st, pcm, n_samples, n_valid_samples, mel_fb, ws,
+                       wgmax, n_mels, n_frames, mel_out);
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
-    hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, keys, n_valid_samples, n_samples,
-                       n_mels, n_frames, gmax);
+    hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, wgmax, n_wg, n_valid_samples,
+                       n_samples, n_mels, n_frames, gmax);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -52,9 +52,16 @@ def _mel_filters_np(n_mels: int) -> np.ndarray:
     return tri.astype(np.float32)
 
 
+_FB_ON_DEVICE = {}
+
+
 def mel_filters(device, n_mels: int = 80) -> torch.Tensor:
+    """One resident copy per (device, n_mels): libwtalign caches the banded form per filterbank pointer."""
     assert n_mels in (80, 128), f"Unsupported n_mels: {n_mels}"
-    return torch.from_numpy(_mel_filters_np(n_mels)).to(device)
+    key = (str(torch.device(device)), n_mels)
+    if key not in _FB_ON_DEVICE:
+        _FB_ON_DEVICE[key] = torch.from_numpy(_mel_filters_np(n_mels)).to(device)
+    return _FB_ON_DEVICE[key]
 
 
 def pad_or_trim(array, length: int = N_SAMPLES, *, axis: int = -1):
