@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+typedef float f4 __attribute__((ext_vector_type(4)));
 template <int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void rd(const float4 *__restrict__ x, size_t n4, float *out) {
     float acc = 0.f;
@@ -10,7 +11,7 @@ __global__ __launch_bounds__(256) void rd(const float4 *__restrict__ x, size_t n
     for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
         float4 r[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) r[u] = NT ? __builtin_nontemporal_load(x + i + u * stride) : x[i + u * stride];
+        for (int u = 0; u < UNROLL; ++u) { if (NT) { f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(x + i + u * stride)); r[u] = make_float4(t.x, t.y, t.z, t.w); } else r[u] = x[i + u * stride]; }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) acc += (r[u].x + r[u].y) + (r[u].z + r[u].w);
     }

@@ -47,7 +47,8 @@ __device__ __forceinline__ void stage_row(const float *__restrict__ src, float *
         if (k < nch) {  // wave-uniform
             const int f = min(k * 64 + lane, F - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + f),
-                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 64), 4, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 64), 4, 0,
+                                             2 /* cpol nt: every logit is read exactly once */);
         }
     }
 }
