@@ -31,7 +31,7 @@ for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy; tools/probes/read_probe: 6.6 read-only)
 
 WORKLOADS = {
     # name: (n_chunks, units per chunk generator)
@@ -295,7 +295,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],
-                         "achievable_peak_measured": 6290.0},
+                         "achievable_copy_GBps_guide": 6290.0, "achievable_read_GBps_probe": 6600.0},
             "stages": stages,
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
