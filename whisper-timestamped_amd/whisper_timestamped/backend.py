@@ -78,3 +78,30 @@ def norm_language(language):
 
 def should_use_space(language) -> bool:
     return norm_language(language) not in ["zh", "ja", "th", "lo", "my", "yue"]
+
+
+@contextmanager
+def gpu_log_mel(device, enabled=True):
+    """While decoding, route openai-whisper's own ``log_mel_spectrogram`` call (whisper/transcribe.py: one call
+    for the whole file, + 30 s of padding, file-global max clamp) through the HIP front end (wt_logmel_batch):
+    the waveform goes to the GPU once and the (n_mels, n_frames) log-mel never exists on the host.
+    Same approach as the reference's forward hooks: the backend is instrumented, not modified."""
+    import sys
+    mod = sys.modules.get("whisper.transcribe")
+    if not enabled or mod is None or not hasattr(mod, "log_mel_spectrogram"):
+        yield False
+        return
+    from . import audio as wt_audio
+    original = mod.log_mel_spectrogram
+
+    def log_mel_on_gpu(audio, n_mels=80, padding=0, device=None):
+        if isinstance(audio, str):
+            audio = whisper().load_audio(audio)
+        return wt_audio.log_mel_spectrogram(audio, n_mels=n_mels, padding=padding, device=_dev)
+
+    _dev = device
+    mod.log_mel_spectrogram = log_mel_on_gpu
+    try:
+        yield True
+    finally:
+        mod.log_mel_spectrogram = original

@@ -34,6 +34,8 @@ logger = logging.getLogger("whisper_timestamped")
 # storage type of the captured cross-attention rows: float32 = what the reference sees (qk.float());
 # float16 halves the HBM bytes of the cost kernel (build-side option, BASELINE config 5; parity quantified in tests)
 RING_DTYPE = torch.float32
+# compute whisper's whole-file log-mel with the HIP front end instead of torch.stft (backend.gpu_log_mel)
+GPU_FRONT_END = True
 
 
 class EfficientSession:
@@ -459,7 +461,7 @@ class EfficientSession:
                     lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
             if self.compute_word_confidence or self.no_speech_threshold is not None:
                 hooks.append(model.decoder.ln.register_forward_hook(self.hook_decoder_output))
-            with torch.no_grad(), backend.attention_weights_exposed():
+            with torch.no_grad(), backend.attention_weights_exposed(), backend.gpu_log_mel(model.device, GPU_FRONT_END):
                 transcription = model.transcribe(audio, **self.opts)
         finally:
             for h in hooks:

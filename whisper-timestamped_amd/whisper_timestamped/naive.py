@@ -97,7 +97,8 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
         hooks.append(model.decoder.ln.register_forward_hook(hook_language))
     try:
         model.alignment_heads = alignment_heads
-        with torch.no_grad(), backend.attention_weights_exposed():
+        from .efficient import GPU_FRONT_END
+        with torch.no_grad(), backend.attention_weights_exposed(), backend.gpu_log_mel(model.device, GPU_FRONT_END):
             transcription = model.transcribe(audio, **whisper_options)
     finally:
         for h in hooks:
