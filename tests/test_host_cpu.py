@@ -138,3 +138,19 @@ def test_alignment_head_tables_match_reference_dumps():
     assert len(ALIGNMENT_HEADS["small.en"][2]) == 19 and len(ALIGNMENT_HEADS["large-v2"][2]) == 23
     ah = alignment_heads_for("large-v3", 32, 20)
     assert ah.is_sparse and ah.coalesce().indices().T.tolist()[0] == [7, 0]
+
+
+def test_package_surface_like_the_reference():
+    """whisper_timestamped/__init__.py of the reference: transcribe / transcribe_timestamped / load_model /
+    __version__ plus re-exported openai-whisper names (its KAT calls whisper_timestamped.tokenizer.get_tokenizer)."""
+    import whisper_double
+    whisper_double.install()
+    import whisper_timestamped as wt
+    assert wt.transcribe is wt.transcribe_timestamped and callable(wt.load_model) and wt.__version__.startswith("1.15.9")
+    tk = wt.tokenizer.get_tokenizer(True, language=None)
+    assert tk.timestamp_begin == 50364
+    assert wt.DecodingOptions is whisper_double.DecodingOptions and wt.Whisper is whisper_double.Whisper
+    for name in ("load_audio", "log_mel_spectrogram", "pad_or_trim", "available_models", "decode", "detect_language"):
+        assert callable(getattr(wt, name))
+    with pytest.raises(AttributeError):
+        wt.no_such_name
