@@ -37,6 +37,12 @@ WORKLOADS = {
     # name: (n_chunks, units per chunk generator)
     "kfull": dict(n_chunks=32, A=8, T=224, F=1500, V=51865, n_mels=80,
                   desc="whisper-base, 32 x 30 s chunks, one (8 heads,224 tokens,1500 frames) unit per chunk, V=51865"),
+    # secondary workloads (not the BASELINE metric config; DESIGN.md section 6 quotes them)
+    "kfull256": dict(n_chunks=256, A=8, T=224, F=1500, V=51865, n_mels=80,
+                     desc="whisper-base shapes, 256 x 30 s chunks (one DTW unit per CU), V=51865"),
+    "largev3_fp16": dict(n_chunks=256, A=10, T=224, F=1500, V=51866, n_mels=128, qk_dtype="f16",
+                         desc="whisper-large-v3 shapes (BASELINE config 5): 256 x 30 s chunks, 10 heads, fp16 QK rows, "
+                              "128 mels, V=51866"),
 }
 
 
@@ -45,6 +51,7 @@ def make_workload(dev, cfg, seed):
     n, A, T, F, V = cfg["n_chunks"], cfg["A"], cfg["T"], cfg["F"], cfg["V"]
     g = torch.Generator(device=dev).manual_seed(seed)
     qk = torch.randn((n, A, T, 1500), generator=g, device=dev, dtype=torch.float32)
+    qk_half = cfg.get("qk_dtype") == "f16"
     # monotone ridge (+6 on a token->frame staircase, 3 frames wide): SURVEY.md 8(d) set K
     rs = np.random.RandomState(seed)
     stairs = np.sort(rs.randint(0, F, size=(n, T)), axis=1)
@@ -53,6 +60,8 @@ def make_workload(dev, cfg, seed):
     ridge = ((fr - st.unsqueeze(-1)).abs() <= 1).to(torch.float32) * 6.0
     qk += ridge.unsqueeze(1)
     del ridge
+    if qk_half:
+        qk = qk.half()
     logits = torch.randn((n * T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
     tokens = torch.randint(0, V, (n * T,), generator=g, device=dev, dtype=torch.int32)
     pcm = torch.randn((n, 480000), generator=g, device=dev, dtype=torch.float32) * 0.1
@@ -118,7 +127,7 @@ def _stage_calls(w):
                     "wt_find_start_padding_batch")
 
     def cost(st):
-        _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+        _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
                                     w["head_idx"].data_ptr(), cfg["A"], 9, 1.0, w["cost"].data_ptr(), st), "wt_cost_batch")
 
     def dtw(st):
@@ -167,7 +176,7 @@ def algorithmic_bytes(cfg):
     return {
         "logmel": n * (480000 * 4 + M * 3000 * 4),
         "padding": n * M * 3000 * 4,
-        "cost": n * (A * T * F * 4 + T * F * 4),          # read selected-head logits once, write cost once
+        "cost": n * (A * T * F * (2 if cfg.get("qk_dtype") == "f16" else 4) + T * F * 4),   # QK rows once, cost once
         "dtw": n * (T * F * 4 + 4 * (T + 1)),             # read cost once, write jumps
         "logprob": n * T * (V * 4 + 8),                   # read each logit row once
     }
@@ -177,7 +186,7 @@ def cpu_baseline(cfg, w, budget_s=20.0):
     """The oracle (CPU restatement of the reference path) on a bounded sample
     of the same workload, host cores of this box, rank 0 only."""
     from oracle import align_ref as O
-    qk = w["qk"][:4].cpu()
+    qk = w["qk"][:4].float().cpu()
     logits = w["logits"][: 4 * cfg["T"]].cpu()
     tokens = w["tokens"][: 4 * cfg["T"]].cpu().numpy()
     pcm = w["pcm"][:4].cpu()
