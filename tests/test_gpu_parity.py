@@ -173,12 +173,15 @@ def test_cost_matches_oracle():
 
 def test_cost_fp16_input_close_to_fp32_oracle():
     """fp16 QK storage is a build-side extension (the reference only sees fp32):
-    quantify against the fp32 oracle on the same (fp16-rounded) logits."""
+    quantify against the fp32 oracle on the same (fp16-rounded) logits.  Even / odd window starts exercise the
+    paired (4-byte aligned) and the element-wise row loads, odd F the unpaired last element."""
     heads = list(range(6))
-    q = synth.synth_qk(7, 6, 20, lo=100, hi=400).astype(np.float16).astype(np.float32)
-    got = run_cost([q], heads, [(100, 400)], [-1], dtype=torch.float16)[0]
-    ref = oracle_cost(q, heads, (100, 400), -1)
-    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-6
+    shapes = [(20, 100, 400), (7, 101, 400), (9, 100, 401), (5, 3, 8), (3, 2, 5), (4, 0, 2), (33, 0, 1500), (12, 11, 1500)]
+    qs = [synth.synth_qk(7 + k, 6, T, lo=s, hi=e).astype(np.float16).astype(np.float32) for k, (T, s, e) in enumerate(shapes)]
+    got = run_cost(qs, heads, [(s, e) for _, s, e in shapes], [-1] * len(shapes), dtype=torch.float16)
+    for q, (T, s, e), g in zip(qs, shapes, got):
+        ref = oracle_cost(q, heads, (s, e), -1)
+        assert np.abs(g - ref).max() / np.abs(ref).max() < 2e-6, (T, s, e)
 
 
 @pytest.mark.parametrize("case", json.load(open(os.path.join(G, "align_cases.json"), encoding="utf-8")),

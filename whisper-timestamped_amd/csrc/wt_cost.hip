@@ -54,6 +54,23 @@ __device__ __forceinline__ void stage_row(const float *__restrict__ src, float *
 }
 template <int C>
 __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float *dst, int F, int nch, int lane) {
+    // fp16 storage (build-side option): two halves per lane and load when the row starts on a 4-byte boundary
+    // (half the load instructions, full 4-byte lanes), element-wise otherwise; converted through registers.
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0 && F >= 2) {  // wave-uniform
+        constexpr int P = C / 2;                         // dword chunks of 64 lanes
+        const int npair = F >> 1;                        // full pairs only: nothing is read past the row
+        __half2 v[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            v[k] = (k * 64 < npair) ? reinterpret_cast<const __half2 *>(src)[min(k * 64 + lane, npair - 1)] : __half2();
+        const float last = __half2float(src[F - 1]);
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            if (k * 64 < npair)                          // (clamped lanes write duplicates beyond the pairs: fixed below)
+                *reinterpret_cast<float2 *>(dst + 4 + 2 * (k * 64 + lane)) = __half22float2(v[k]);
+        if (lane == 0) dst[4 + F - 1] = last;            // odd F: the unpaired last element (same-wave LDS order)
+        return;
+    }
     float v[C];
 #pragma unroll
     for (int k = 0; k < C; ++k) v[k] = (k < nch) ? __half2float(src[min(k * 64 + lane, F - 1)]) : 0.f;
