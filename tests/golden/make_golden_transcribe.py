@@ -136,6 +136,18 @@ def case_list():
     C.append(dict(name="vad_explicit_islands", model="tiny", audio_s=30.0, audio_seed=18,
                   opts=dict(language="en", vad=[(2.0, 9.5), (14.0, 21.25)]),
                   script=[window_script(ML, EOT_ML, [seg(33, 5, 8, 330), seg(34, 340, 9, 700)], "eot")]))
+    C.append(dict(name="initial_prompt_and_translate", model="tiny", audio_s=38.0, audio_seed=19,
+                  opts=dict(language="fr", task="translate", initial_prompt="So, uh, I guess"),
+                  script=[window_script(ML, EOT_ML, [seg(36, 4, 7, 320), seg(37, 330, 6, 900)], "pair"),
+                          window_script(ML, EOT_ML, [seg(38, 10, 8, 450)], "eot")]))
+    C.append(dict(name="english_only_no_trust_no_condition", model="tiny.en", audio_s=35.0, audio_seed=21,
+                  opts=dict(language="en", trust_whisper_timestamps=False, condition_on_previous_text=False,
+                            suppress_tokens="11,13"),
+                  script=[window_script(EN, EOT_EN, [seg(44, 0, 6, 500), seg(46, 520, 7, 1200)], "pair"),
+                          window_script(EN, EOT_EN, [seg(48, 20, 8, 400)], "eot")]))
+    C.append(dict(name="language_detection_no_trust", model="tiny", audio_s=9.0, audio_seed=22,
+                  opts=dict(language=None, trust_whisper_timestamps=False),
+                  script=[window_script(ML, EOT_ML, [seg(50, 15, 7, 200), seg(52, 210, 6, 430)], "eot")]))
     # ---- naive strategy (transcribe, then teacher-forced re-run) -------------------------------------
     C.append(dict(name="naive_greedy", model="tiny", audio_s=12.0, audio_seed=14,
                   opts=dict(language="en", naive_approach=True),
@@ -149,6 +161,9 @@ def case_list():
                   opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False,
                             include_punctuation_in_confidence=True),
                   script=[window_script(ML, EOT_ML, [seg(31, 5, 8, 250), (260, [6455, 11, 2232, 13], 600)], "eot")]))
+    C.append(dict(name="naive_sampling_best_of", model="tiny", audio_s=11.0, audio_seed=23,
+                  opts=dict(language="en", temperature=0.5, best_of=2),
+                  script=[window_script(ML, EOT_ML, [seg(55, 6, 7, 260), seg(57, 270, 8, 520)], "eot")]))
     C.append(dict(name="naive_language_detection", model="tiny", audio_s=8.0, audio_seed=17,
                   opts=dict(language=None, temperature=(0.0, 0.4)),
                   script=[window_script(ML, EOT_ML, [seg(32, 6, 7, 330)], "eot")]))

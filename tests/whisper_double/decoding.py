@@ -177,7 +177,7 @@ class GreedyDecoder:
             next_tokens = logits.argmax(dim=-1)
         else:
             next_tokens = Categorical(logits=logits / self.temperature).sample()
-        if _SCRIPT is not None:
+        if _SCRIPT is not None and tokens.shape[0] == 1:    # (several hypotheses: forced at the result level, see run())
             next_tokens = torch.tensor([_SCRIPT.pick(int(t), logits[k], self.eot) for k, t in enumerate(next_tokens.tolist())],
                                        device=logits.device)
         logprobs = F.log_softmax(logits.float(), dim=-1)
@@ -456,7 +456,7 @@ class DecodingTask:
         tokens = [[t[self.sample_begin: (t == tokenizer.eot).nonzero()[0, 0]] for t in s] for s in tokens]
         selected = self.sequence_ranker.rank(tokens, sum_logprobs)
         tokens = [t[i].tolist() for i, t in zip(selected, tokens)]
-        if _SCRIPT is not None and isinstance(self.decoder, BeamSearchDecoder):
+        if _SCRIPT is not None and self.n_group > 1:      # beam search / best_of: the scripted window replaces the result
             tokens = [_SCRIPT.final_tokens(t, tokenizer.eot) for t in tokens]
         texts = [tokenizer.decode(t).strip() for t in tokens]
         sum_logprobs = [lp[i] for i, lp in zip(selected, sum_logprobs)]
