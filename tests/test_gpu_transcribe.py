@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from golden import make_golden_transcribe as G
-from test_transcribe_host import CASES, compare, run_case
+from test_transcribe_host import CASES, compare, is_sampled, run_case
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def _report(name, dt, dc):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_transcribe_matches_reference_output(case):
     got = run_case(copy.deepcopy(case), device="cuda:0")
-    dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
+    dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4, sampled=is_sampled(case))
     _report(case["name"], dt, dc)
 
 
