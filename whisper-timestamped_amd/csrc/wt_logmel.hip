@@ -10,14 +10,19 @@
 //
 // Not a GEMM: the 400-point real DFT is factored 20 x 20 (Cooley-Tukey, n =
 // 20*n1 + n2, k = k1 + 20*k2).  Twenty lanes own one frame; each lane does a
-// radix-20 butterfly entirely in registers with the 20th roots of unity as
-// scalar (SGPR) operands, the W400 twiddle comes from a 3.2 KB LDS table, the
-// transposition between the two stages goes through LDS.  Three frames per
-// wave, twelve per 256-thread workgroup, 250 workgroups per 30 s chunk.
-// ~52 kFLOP per frame instead of 322 kFLOP for the direct DFT.
-// Pass 1 writes log10(mel) and an atomic per-chunk max; pass 2 applies the
-// clamp/scale and the zero padding.  Algorithmic bytes: 480000*4 read +
-// n_mels*3000*4 written per chunk (the intermediate is re-read from L2).
+// radix-20 butterfly entirely in registers; both stages pair n with 20-n and
+// k with 10-k, and the 20th roots of unity are compile-time constants, so the
+// zeros and +-1 fold away: 324 multiply-adds per lane instead of 1240.  The
+// W400 twiddle comes from a 3.2 KB LDS table, the transposition between the
+// two stages goes through LDS.  Three frames per wave, twelve per 256-thread
+// workgroup (39 KB of LDS: 16 waves per CU), 250 workgroups per 30 s chunk.
+// ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT; the kernel is
+// VALU-issue bound (profiles/r1l_sq_counters.txt).
+// Pass 1 writes log10(mel) and one maximum per workgroup (no atomics, nothing
+// to reset); pass 2 reduces them per chunk, applies the clamp/scale and the
+// zero padding.  Algorithmic bytes: 480000*4 read + n_mels*3000*4 written per
+// chunk (the intermediate is re-read from L2).  The banded form of the
+// filterbank is cached per stream and filterbank pointer.
 #include <cmath>
 #include <mutex>
 
