@@ -40,6 +40,9 @@ WORKLOADS = {
     # secondary workloads (not the BASELINE metric config; DESIGN.md section 6 quotes them)
     "kfull256": dict(n_chunks=256, A=8, T=224, F=1500, V=51865, n_mels=80,
                      desc="whisper-base shapes, 256 x 30 s chunks (one DTW unit per CU), V=51865"),
+    "kreal": dict(n_chunks=32, A=8, T=None, F=None, V=51865, n_mels=80, units_per_chunk=5,
+                  desc="whisper-base, 32 x 30 s chunks, 5 segments per chunk with the (T, F) mix measured on the reference "
+                       "goldens (T p50 11 / p90 30, F p50 144 / p90 352), V=51865"),
     "largev3_fp16": dict(n_chunks=256, A=10, T=224, F=1500, V=51866, n_mels=128, qk_dtype="f16",
                          desc="whisper-large-v3 shapes (BASELINE config 5): 256 x 30 s chunks, 10 heads, fp16 QK rows, "
                               "128 mels, V=51866"),
@@ -48,6 +51,8 @@ WORKLOADS = {
 
 def make_workload(dev, cfg, seed):
     from whisper_timestamped import _lib
+    if cfg.get("units_per_chunk"):
+        return make_workload_kreal(dev, cfg, seed)
     n, A, T, F, V = cfg["n_chunks"], cfg["A"], cfg["T"], cfg["F"], cfg["V"]
     g = torch.Generator(device=dev).manual_seed(seed)
     qk = torch.randn((n, A, T, 1500), generator=g, device=dev, dtype=torch.float32)
@@ -86,6 +91,55 @@ def make_workload(dev, cfg, seed):
     return w
 
 
+def make_workload_kreal(dev, cfg, seed):
+    """Several short units per chunk: each unit is a window [start, start+F) of T consecutive rows of the chunk's
+    captured QK block (the layout the capture ring produces)."""
+    from whisper_timestamped import _lib
+    from whisper_timestamped.audio import mel_filters
+    import synth
+    n, A, V, U = cfg["n_chunks"], cfg["A"], cfg["V"], cfg["units_per_chunk"]
+    g = torch.Generator(device=dev).manual_seed(seed)
+    Ts, Fs = synth.draw_real_shapes(seed, n * U)
+    rows_per_chunk = 256
+    qk = torch.randn((n, A, rows_per_chunk, 1500), generator=g, device=dev, dtype=torch.float32)
+    descs = _lib.make_descs(n * U)
+    rs = np.random.RandomState(seed)
+    stairs, tot_T = [], 0
+    for b in range(n):
+        row = 0
+        for u in range(U):
+            k = b * U + u
+            T, F = int(min(Ts[k], rows_per_chunk - row - 1)), int(Fs[k])
+            T = max(T, 2)
+            F = max(F, T + 1)
+            start = int(rs.randint(0, 1500 - F + 1))
+            st = np.sort(rs.randint(0, F, size=T))
+            for t in range(T):
+                a, e = start + max(st[t] - 1, 0), start + min(st[t] + 2, F)
+                qk[b, :, row + t, a:e] += 6.0
+            d = descs[k]
+            d["qk_offset"] = (b * A * rows_per_chunk + row) * 1500
+            d["head_stride"], d["row_stride"] = rows_per_chunk * 1500, 1500
+            d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, start, -1
+            stairs.append(st)
+            row += T
+            tot_T += T
+    n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
+    logits = torch.randn((tot_T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
+    tokens = torch.randint(0, V, (tot_T,), generator=g, device=dev, dtype=torch.int32)
+    pcm = torch.randn((n, 480000), generator=g, device=dev, dtype=torch.float32) * 0.1
+    cfg = dict(cfg, n_rows=tot_T, units=[(int(d["T"]), int(d["F"])) for d in descs])
+    return dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=mel_filters(dev, cfg["n_mels"]), descs=descs,
+                descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
+                cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
+                jumps=torch.empty(n_jumps, dtype=torch.int32, device=dev),
+                logprob=torch.empty(tot_T, dtype=torch.float32, device=dev),
+                mel=torch.empty((n, cfg["n_mels"], 3000), dtype=torch.float32, device=dev),
+                gmax=torch.empty(n, dtype=torch.float32, device=dev), pad=torch.empty(n, dtype=torch.int32, device=dev),
+                host_jumps=torch.empty(n_jumps, dtype=torch.int32).pin_memory(),
+                host_logprob=torch.empty(tot_T, dtype=torch.float32).pin_memory(), stairs=stairs)
+
+
 STAGES = ["logmel", "padding", "cost", "dtw", "logprob"]
 # kernels of each stage as rocprofv3 names them (profiles/*traffic.json keys)
 STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel"],
@@ -116,7 +170,9 @@ def _stage_calls(w):
     from whisper_timestamped import _lib
     L = _lib.load()
     cfg = w["cfg"]
-    n, T, V = cfg["n_chunks"], cfg["T"], cfg["V"]
+    n, V = cfg["n_chunks"], cfg["V"]
+    n_units = len(w["descs"])
+    n_rows = cfg.get("n_rows") or n * cfg["T"]
 
     def logmel(st):
         _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, 0, w["fb"].data_ptr(), cfg["n_mels"], 3000,
@@ -127,15 +183,15 @@ def _stage_calls(w):
                     "wt_find_start_padding_batch")
 
     def cost(st):
-        _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+        _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n_units,
                                     w["head_idx"].data_ptr(), cfg["A"], 9, 1.0, w["cost"].data_ptr(), st), "wt_cost_batch")
 
     def dtw(st):
-        _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n,
+        _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n_units,
                                    w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
 
     def logprob(st):
-        _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n * T, V, w["tokens"].data_ptr(), 0, 0,
+        _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n_rows, V, w["tokens"].data_ptr(), 0, 0,
                                               w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
 
     return dict(logmel=logmel, padding=padding, cost=cost, dtw=dtw, logprob=logprob)
@@ -186,13 +242,17 @@ def run_step(w, ev=None, streams=None):
 
 def algorithmic_bytes(cfg):
     """Per launch (= per step on one rank), SURVEY.md 8(d)."""
-    n, A, T, F, V, M = cfg["n_chunks"], cfg["A"], cfg["T"], cfg["F"], cfg["V"], cfg["n_mels"]
+    n, A, V, M = cfg["n_chunks"], cfg["A"], cfg["V"], cfg["n_mels"]
+    units = cfg.get("units") or [(cfg["T"], cfg["F"])] * n
+    s_in = 2 if cfg.get("qk_dtype") == "f16" else 4
+    tf = sum(t * f for t, f in units)
+    rows = sum(t for t, _ in units)
     return {
         "logmel": n * (480000 * 4 + M * 3000 * 4),
         "padding": n * M * 3000 * 4,
-        "cost": n * (A * T * F * (2 if cfg.get("qk_dtype") == "f16" else 4) + T * F * 4),   # QK rows once, cost once
-        "dtw": n * (T * F * 4 + 4 * (T + 1)),             # read cost once, write jumps
-        "logprob": n * T * (V * 4 + 8),                   # read each logit row once
+        "cost": A * tf * s_in + tf * 4,                    # selected-head logits once, cost once
+        "dtw": tf * 4 + 4 * (rows + len(units)),           # read cost once, write jumps
+        "logprob": rows * (V * 4 + 8),                     # read each logit row once
     }
 
 
@@ -250,7 +310,8 @@ def main():
 
     cfg = WORKLOADS[args.workload]
     w = make_workload(dev, cfg, seed=1234 + rank)
-    n, T = cfg["n_chunks"], cfg["T"]
+    n = cfg["n_chunks"]
+    cfg = w["cfg"]
 
     gather_buf = None
     if world > 1:
@@ -293,9 +354,14 @@ def main():
 
     # sanity inside the bench: the ridge is recovered and log-probs are finite
     torch.cuda.synchronize()
-    j = w["host_jumps"].numpy().reshape(n, T + 1)
-    assert (j[:, 0] == 0).all() and (j[:, -1] == cfg["F"] - 1).all() and (np.diff(j, axis=1) >= 0).all()
-    assert np.median(np.abs(j[:, :-1] - w["stairs"])) <= 3
+    hj = w["host_jumps"].numpy()
+    devs = []
+    for k, d in enumerate(w["descs"]):
+        Tk, Fk, j0 = int(d["T"]), int(d["F"]), int(d["jumps_offset"])
+        j = hj[j0:j0 + Tk + 1]
+        assert j[0] == 0 and j[-1] == Fk - 1 and (np.diff(j) >= 0).all()
+        devs.append(np.abs(j[:-1] - np.asarray(w["stairs"][k])))
+    assert np.median(np.concatenate(devs)) <= 3
     assert np.isfinite(w["host_logprob"].numpy()).all()
 
     if rank == 0:
@@ -326,7 +392,7 @@ def main():
                          "achievable_copy_GBps_guide": 6290.0, "achievable_read_GBps_probe": 6600.0},
             "stages": stages,
         }
-        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and not cfg.get("units"):      # rank 0 at N=1 only (fixed-shape workloads)
             out["cpu_baseline"] = cpu_baseline(cfg, w)
         print(json.dumps(out))
     if dist is not None:
