@@ -102,9 +102,8 @@ def make_workload_kreal(dev, cfg, seed):
     Ts, Fs = synth.draw_real_shapes(seed, n * U)
     rows_per_chunk = 256
     qk = torch.randn((n, A, rows_per_chunk, 1500), generator=g, device=dev, dtype=torch.float32)
-    descs = _lib.make_descs(n * U)
     rs = np.random.RandomState(seed)
-    stairs, tot_T = [], 0
+    raw, tot_T = [], 0
     for b in range(n):
         row = 0
         for u in range(U):
@@ -117,13 +116,17 @@ def make_workload_kreal(dev, cfg, seed):
             for t in range(T):
                 a, e = start + max(st[t] - 1, 0), start + min(st[t] + 2, F)
                 qk[b, :, row + t, a:e] += 6.0
-            d = descs[k]
-            d["qk_offset"] = (b * A * rows_per_chunk + row) * 1500
-            d["head_stride"], d["row_stride"] = rows_per_chunk * 1500, 1500
-            d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, start, -1
-            stairs.append(st)
+            raw.append(dict(qk_offset=(b * A * rows_per_chunk + row) * 1500, T=T, F=F, start=start, stairs=st))
             row += T
             tot_T += T
+    order = _lib.launch_order([(r["T"], r["F"]) for r in raw])      # grouped by F class, as AlignmentBatch does
+    descs = _lib.make_descs(n * U)
+    stairs = []
+    for d, i in zip(descs, order):
+        r = raw[i]
+        d["qk_offset"], d["head_stride"], d["row_stride"] = r["qk_offset"], rows_per_chunk * 1500, 1500
+        d["T"], d["F"], d["start_token"], d["pad_from"] = r["T"], r["F"], r["start"], -1
+        stairs.append(r["stairs"])
     n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
     logits = torch.randn((tot_T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
     tokens = torch.randint(0, V, (tot_T,), generator=g, device=dev, dtype=torch.int32)

@@ -83,7 +83,7 @@ __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float 
 template <int C, typename QT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                       const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                      float *__restrict__ cost, unsigned *__restrict__ segstate) {
+                                                      float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0) {
     constexpr int CAP = C * 64;
     constexpr int FLO = (C - 4) * 64;
     constexpr int BUF = CAP + 8;
@@ -91,12 +91,13 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const wt_seg_desc d = segs[blockIdx.y];
+    const int unit = unit0 + blockIdx.y;
+    const wt_seg_desc d = segs[unit];
     const int F = d.F;
     const int t = blockIdx.x * 4 + wave;
     if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
     const int nch = (F + 63) >> 6;
-    if (t == 0 && lane == 0) segstate[blockIdx.y] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
+    if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
 
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     // halo duty of lanes 0..7: scipy 'reflect' source index of positions -4..-1 and F..F+3
@@ -191,8 +192,9 @@ constexpr int CN_WAVES = 16;
 constexpr int CN_ROWS = (WT_MAX_TOKENS + CN_WAVES - 1) / CN_WAVES;
 __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restrict__ cost,
                                                                 const wt_seg_desc *__restrict__ segs,
-                                                                unsigned *__restrict__ segmax) {
-    const wt_seg_desc d = segs[blockIdx.y];
+                                                                unsigned *__restrict__ segmax, int unit0) {
+    const int unit = unit0 + blockIdx.y;
+    const wt_seg_desc d = segs[unit];
     const int F = d.F, T = d.T;
     if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
     __shared__ double ssq[CN_WAVES][64];
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
         // fire-and-forget (no return value, nobody waits for it).  Folding cost[0,0] = min into this kernel was
         // measured and dropped: a last-tile-done protocol needs either a release fence (writes the L2 back: +30 %
         // on the stage) or a returning CAS on the critical path (colnorm 25 -> 68 us); a 4 us kernel is cheaper.
-        if (lane == 0) atomicMax(segmax + blockIdx.y, __float_as_uint(r));
+        if (lane == 0) atomicMax(segmax + unit, __float_as_uint(r));
     }
     __syncthreads();
     const float norm = snorm[lane];
@@ -256,20 +258,39 @@ __global__ void fix00_kernel(float *__restrict__ cost, const wt_seg_desc *__rest
     if (s < n_seg) cost[segs[s].cost_offset] = -__uint_as_float(segmax[s]);
 }
 
+// Units of one F class (C = 4*ceil(F/256) elements per lane) share a rowmean instantiation.  When the caller passes
+// the units grouped by class (the host layer sorts them), each class is launched over ITS units only, with its own
+// largest T and F; otherwise every class launch spans all units and foreign blocks return at once (correct, but a
+// batch of many short units then launches mostly empty blocks: 75 us instead of 25 for 160 real-shape units).
+struct ClassRange {
+    int lo = 0, n = 0, maxT = 0, maxF = 0;
+    bool any = false;
+};
+static bool class_ranges(const wt_seg_desc *segs_host, int n_seg, ClassRange (&cls)[7]) {
+    bool grouped = true;
+    int last = -1;
+    for (int i = 0; i < n_seg; ++i) {
+        const int c = (segs_host[i].F + 255) / 256 - 1;
+        ClassRange &r = cls[c];
+        if (!r.any) { r.any = true; r.lo = i; }
+        else if (last != c) grouped = false;   // class c seen before, with another class in between
+        r.n = i - r.lo + 1;
+        if (segs_host[i].T > r.maxT) r.maxT = segs_host[i].T;
+        if (segs_host[i].F > r.maxF) r.maxF = segs_host[i].F;
+        last = c;
+    }
+    return grouped;
+}
+
 template <typename QT>
-static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, const ClassRange (&cls)[7], bool grouped,
                           const int32_t *head_idx, int n_heads, float qk_scale, float *cost, unsigned *segstate,
                           hipStream_t st) {
-    int maxT[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < n_seg; ++i) {
-        const int c = (segs_host[i].F + 255) / 256 - 1;  // C = 4*(c+1)
-        if (segs_host[i].T > maxT[c]) maxT[c] = segs_host[i].T;
-    }
 #define WT_LAUNCH_ROWMEAN(CI)                                                                                       \
-    if (maxT[CI] > 0) {                                                                                             \
-        dim3 grid((maxT[CI] + 3) / 4, n_seg);                                                                       \
+    if (cls[CI].any) {                                                                                              \
+        dim3 grid((cls[CI].maxT + 3) / 4, grouped ? cls[CI].n : n_seg);                                             \
         hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx,      \
-                           n_heads, qk_scale, cost, segstate);                                                      \
+                           n_heads, qk_scale, cost, segstate, grouped ? cls[CI].lo : 0);                            \
     }
     WT_LAUNCH_ROWMEAN(0)
     WT_LAUNCH_ROWMEAN(1)
@@ -306,16 +327,26 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     unsigned *segstate = nullptr;  // per unit max |cost| bits: zeroed by rowmean, merged by colnorm, used by fix00
     int rc = scratch(st, (size_t)n_seg * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
+    ClassRange cls[7];
+    const bool grouped = class_ranges(segs_host, n_seg, cls);
     if (qk_dtype == WT_DTYPE_F32)
-        rc = launch_rowmean((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);
+        rc = launch_rowmean((const float *)qk, segs_dev, n_seg, cls, grouped, head_idx, n_heads, qk_scale, cost, segstate, st);
     else if (qk_dtype == WT_DTYPE_F16)
-        rc = launch_rowmean((const __half *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, segstate, st);
+        rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, cls, grouped, head_idx, n_heads, qk_scale, cost, segstate, st);
     else {
         set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
         return WT_E_BADARG;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate);
+    if (grouped) {
+        for (int c = 0; c < 7; ++c)
+            if (cls[c].any)
+                hipLaunchKernelGGL(colnorm_kernel, dim3((cls[c].maxF + 63) / 64, cls[c].n), dim3(64 * CN_WAVES), 0, st, cost,
+                                   segs_dev, segstate, cls[c].lo);
+    } else {
+        hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate,
+                           0);
+    }
     hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segstate, n_seg);
     WT_HIP(hipGetLastError());
     return WT_OK;

@@ -96,6 +96,12 @@ def descs_to_device(descs: np.ndarray, device) -> torch.Tensor:
     return raw.to(device, non_blocking=False)
 
 
+def launch_order(shapes):
+    """Order in which to hand units to the library: grouped by the cost kernel's F class (ceil(F/256)), longest
+    first inside a class.  wt_cost_batch then launches every class over its own units only (wt_cost.hip)."""
+    return sorted(range(len(shapes)), key=lambda i: ((shapes[i][1] + 255) // 256, -shapes[i][0], -shapes[i][1], i))
+
+
 def layout_outputs(descs: np.ndarray):
     """Fill cost/jumps/path offsets (cost slots 16-byte aligned).  Returns totals; the cost total includes the
     16 bytes of read slack wt_dtw_batch asks for (include/wtalign.h)."""

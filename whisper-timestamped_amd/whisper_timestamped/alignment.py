@@ -176,9 +176,11 @@ class AlignmentBatch:
         return unit
 
     def run(self):
-        units = self.units
-        if not units:
+        if not self.units:
             return []
+        # the library wants units grouped by F class; results are handed back in the caller's order
+        order = _lib.launch_order([(u.T, u.F) for u in self.units])
+        units = [self.units[i] for i in order]
         dev = units[0].qk.device
         dt = units[0].qk.dtype
         esz = units[0].qk.element_size()
@@ -215,23 +217,27 @@ class AlignmentBatch:
         jumps_host = jumps.cpu().numpy()                       # the one device->host sync of the batch
         need_cost = self.keep_cost or any(u.detect_disfluencies for u in units)
         cost_host = cost.cpu().numpy() if need_cost else None
-        out = []
-        for d, u in zip(descs, units):
+        out = [None] * len(units)
+        self._slot = [0] * len(units)                # caller's unit index -> descriptor index
+        for k, (d, u) in enumerate(zip(descs, units)):
             j0 = int(d["jumps_offset"])
             jm = jumps_host[j0:j0 + u.T + 1].astype(np.int64)
             cm = None
             if cost_host is not None:
                 c0 = int(d["cost_offset"])
                 cm = cost_host[c0:c0 + u.T * u.F].reshape(u.T, u.F)
-            out.append(finish_unit(u, jm, cm))
+            out[order[k]] = finish_unit(u, jm, cm)
+            self._slot[order[k]] = k
         return out
 
     def unit_cost(self, k):
+        k = self._slot[k]
         d = self.descs[k]
         c0 = int(d["cost_offset"])
         return self.cost[c0:c0 + int(d["T"]) * int(d["F"])].reshape(int(d["T"]), int(d["F"]))
 
     def unit_path(self, k):
+        k = self._slot[k]
         d = self.descs[k]
         n = int(self.path_len[k])
         p0 = int(d["path_offset"])
