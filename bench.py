@@ -209,7 +209,26 @@ def run_step(w, ev=None, streams=None):
     kernels are launched on.  streams: None = everything on the current stream, in order; else 3 torch streams."""
     calls = w.setdefault("_calls", _stage_calls(w))
     main = torch.cuda.current_stream()
-    if isinstance(streams, tuple) and streams[0] == "dtw":
+    if isinstance(streams, tuple) and streams[0] == "dtw_logmel":
+        # cost -> [DTW on a side stream: 32 CUs, 137 KB of LDS each, latency-bound] || [log-mel: VALU-bound, fills
+        # the other 224 CUs; its workgroups do not fit next to a DTW workgroup] -> log-prob alone (HBM-bound)
+        side = streams[1]
+        if ev: ev["cost"][0].record(main)
+        calls["cost"](main.cuda_stream)
+        if ev: ev["cost"][1].record(main)
+        side.wait_stream(main)
+        if ev: ev["dtw"][0].record(side)
+        calls["dtw"](side.cuda_stream)
+        if ev: ev["dtw"][1].record(side)
+        for stage in ("logmel", "padding"):
+            if ev: ev[stage][0].record(main)
+            calls[stage](main.cuda_stream)
+            if ev: ev[stage][1].record(main)
+        main.wait_stream(side)
+        if ev: ev["logprob"][0].record(main)
+        calls["logprob"](main.cuda_stream)
+        if ev: ev["logprob"][1].record(main)
+    elif isinstance(streams, tuple) and streams[0] == "dtw":
         side = streams[1]
         for stage in ("logmel", "padding", "cost"):
             if ev: ev[stage][0].record(main)
@@ -294,7 +313,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw"],
+    ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
     args = ap.parse_args()
@@ -306,9 +325,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("WT_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = WORKLOADS[args.workload]
@@ -317,15 +338,15 @@ def main():
     cfg = w["cfg"]
 
     gather_buf = None
-    if world > 1:
+    if world > 1 or force_dist:
         from whisper_timestamped.sharding import ResultGatherer
         gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev)
 
     streams = None
     if args.overlap == "lanes":
         streams = [torch.cuda.Stream(device=dev) for _ in LANES]
-    elif args.overlap == "dtw":
-        streams = "dtw", torch.cuda.Stream(device=dev)
+    elif args.overlap in ("dtw", "dtw_logmel"):
+        streams = args.overlap, torch.cuda.Stream(device=dev)
 
     def full_step(ev=None):
         run_step(w, ev, streams)
@@ -387,7 +408,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
-                       "streams": {"none": 1, "lanes": 3, "dtw": 2}[args.overlap],
+                       "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2}[args.overlap],
                        "result_gather": "rccl gather to rank 0" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
