@@ -318,6 +318,11 @@ def main():
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything libraries print meanwhile (RCCL's init banner ...) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -418,7 +423,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and not cfg.get("units"):      # rank 0 at N=1 only (fixed-shape workloads)
             out["cpu_baseline"] = cpu_baseline(cfg, w)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
