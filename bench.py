@@ -313,6 +313,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N>1: result records of this many steps travel to rank 0 in one RCCL gather")
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
@@ -345,7 +347,7 @@ def main():
     gather_buf = None
     if world > 1 or force_dist:
         from whisper_timestamped.sharding import ResultGatherer
-        gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev)
+        gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev, every=args.gather_every)
 
     streams = None
     if args.overlap == "lanes":
@@ -414,7 +416,7 @@ def main():
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2}[args.overlap],
-                       "result_gather": "rccl gather to rank 0" if world > 1 else "none"},
+                       "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],

@@ -77,13 +77,14 @@ def _worker(rank, world, port, out_path):
             lps[ol:ol + T] = torch.from_numpy(lp)
             oj += T + 1
             ol += T
-        g = ResultGatherer(dist, cap_j, cap_l, "cpu")
-        for step in range(3):                     # the double-buffered async path: earlier steps carry other payloads
-            g.gather(jumps if step == 2 else jumps + step + 1, lps)
+        g = ResultGatherer(dist, cap_j, cap_l, "cpu", every=2)
+        for step in range(5):                     # double-buffered async path, 2 records per message (+ a partial one)
+            g.gather(jumps if step == 4 else jumps + step + 1, lps)
+        g.drain()                                 # the partial message (step 4) is record 0 of the newest gather
         if rank == 0:
             got = {}
             for r in range(world):
-                bj, bl = g.unpack(r)
+                bj, bl = g.unpack(r, step=0)
                 oj = ol = 0
                 for i in parts[r]:
                     T, F = units[i]
