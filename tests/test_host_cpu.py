@@ -154,3 +154,20 @@ def test_package_surface_like_the_reference():
         assert callable(getattr(wt, name))
     with pytest.raises(AttributeError):
         wt.no_such_name
+
+
+def test_gpu_log_mel_patch_is_scoped():
+    """backend.gpu_log_mel instruments the backend's transcribe module only inside the context (also on errors)."""
+    import sys
+    import whisper_double
+    whisper_double.install()
+    from whisper_timestamped import backend
+    mod = sys.modules["whisper.transcribe"]
+    original = mod.log_mel_spectrogram
+    with backend.gpu_log_mel("cuda:0", enabled=False) as on:
+        assert on is False and mod.log_mel_spectrogram is original
+    with pytest.raises(RuntimeError):
+        with backend.gpu_log_mel("cuda:0", enabled=True) as on:
+            assert on is True and mod.log_mel_spectrogram is not original
+            raise RuntimeError("decode failed")
+    assert mod.log_mel_spectrogram is original
