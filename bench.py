@@ -49,6 +49,15 @@ WORKLOADS = {
 }
 
 
+def result_buffers(n_jumps, n_logprob, dev):
+    """The KB-sized results of a step live in ONE device record (jumps, then the log-probs) so that a single async
+    copy brings them to the host (and a single message carries them to rank 0)."""
+    rec = torch.empty(n_jumps + n_logprob, dtype=torch.int32, device=dev)
+    host = torch.empty(n_jumps + n_logprob, dtype=torch.int32).pin_memory()
+    return dict(result=rec, jumps=rec[:n_jumps], logprob=rec[n_jumps:].view(torch.float32), host_result=host,
+                host_jumps=host[:n_jumps], host_logprob=host[n_jumps:].view(torch.float32))
+
+
 def make_workload(dev, cfg, seed):
     from whisper_timestamped import _lib
     if cfg.get("units_per_chunk"):
@@ -80,13 +89,10 @@ def make_workload(dev, cfg, seed):
     w = dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=fb, descs=descs,
              descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
              cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
-             jumps=torch.empty(n_jumps, dtype=torch.int32, device=dev),
-             logprob=torch.empty(n * T, dtype=torch.float32, device=dev),
+             **result_buffers(n_jumps, n * T, dev),
              mel=torch.empty((n, cfg["n_mels"], 3000), dtype=torch.float32, device=dev),
              gmax=torch.empty(n, dtype=torch.float32, device=dev),
              pad=torch.empty(n, dtype=torch.int32, device=dev),
-             host_jumps=torch.empty(n_jumps, dtype=torch.int32).pin_memory(),
-             host_logprob=torch.empty(n * T, dtype=torch.float32).pin_memory(),
              stairs=stairs)
     return w
 
@@ -135,12 +141,10 @@ def make_workload_kreal(dev, cfg, seed):
     return dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=mel_filters(dev, cfg["n_mels"]), descs=descs,
                 descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
                 cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
-                jumps=torch.empty(n_jumps, dtype=torch.int32, device=dev),
-                logprob=torch.empty(tot_T, dtype=torch.float32, device=dev),
+                **result_buffers(n_jumps, tot_T, dev),
                 mel=torch.empty((n, cfg["n_mels"], 3000), dtype=torch.float32, device=dev),
                 gmax=torch.empty(n, dtype=torch.float32, device=dev), pad=torch.empty(n, dtype=torch.int32, device=dev),
-                host_jumps=torch.empty(n_jumps, dtype=torch.int32).pin_memory(),
-                host_logprob=torch.empty(tot_T, dtype=torch.float32).pin_memory(), stairs=stairs)
+                stairs=stairs)
 
 
 STAGES = ["logmel", "padding", "cost", "dtw", "logprob"]
@@ -260,8 +264,7 @@ def run_step(w, ev=None, streams=None):
                 calls[stage](s.cuda_stream)
                 if ev: ev[stage][1].record(s)
             main.wait_stream(s)
-    w["host_jumps"].copy_(w["jumps"], non_blocking=True)
-    w["host_logprob"].copy_(w["logprob"], non_blocking=True)
+    w["host_result"].copy_(w["result"], non_blocking=True)
 
 
 def algorithmic_bytes(cfg):
