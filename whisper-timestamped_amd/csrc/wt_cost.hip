@@ -79,13 +79,13 @@ __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float 
         if (k < nch) dst[4 + k * 64 + lane] = v[k];
 }
 
-// C = elements per lane = 4*ceil(F/256); one instantiation serves (C-4)*64 < F <= C*64.
+// C = elements per lane; an instantiation can serve any F <= C*64 (the launch passes the F range it is used for).
 template <int C, typename QT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                       const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                      float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0) {
+                                                      float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
+                                                      int f_lo, int f_hi) {
     constexpr int CAP = C * 64;
-    constexpr int FLO = (C - 4) * 64;
     constexpr int BUF = CAP + 8;
     __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];  // per wave: double-buffered row
 
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const wt_seg_desc d = segs[unit];
     const int F = d.F;
     const int t = blockIdx.x * 4 + wave;
-    if (F <= FLO || F > CAP || t >= d.T) return;  // wave-uniform
+    if (F <= f_lo || F > f_hi || t >= d.T) return;  // wave-uniform; the host guarantees f_hi <= CAP
     const int nch = (F + 63) >> 6;
     if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
 
@@ -282,24 +282,64 @@ static bool class_ranges(const wt_seg_desc *segs_host, int n_seg, ClassRange (&c
     return grouped;
 }
 
+// Launch plan: at most TWO rowmean (and colnorm) launches per call -- "short" windows (F <= 512) with the 8-elements-
+// per-lane instantiation and everything longer with the instantiation of the longest window present -- because a
+// mixed batch is launch-bound, not work-bound (160 real-shape units: 11 launches 68 us -> 5 launches).  A batch
+// whose units all fall in one class keeps that class's exact instantiation.
+struct LaunchGroup {
+    int ci = -1;            // instantiation index: C = 4 * (ci + 1)
+    int lo = 0, n = 0;      // unit range when grouped
+    int maxT = 0, maxF = 0, f_lo = 0, f_hi = 0;
+};
+static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2]) {
+    int first = -1, last = -1, present = 0;
+    for (int c = 0; c < 7; ++c)
+        if (cls[c].any) { if (first < 0) first = c; last = c; ++present; }
+    auto fill = [&](LaunchGroup &out, int c0, int c1, int ci) {
+        out = LaunchGroup();
+        out.ci = ci;
+        out.f_lo = c0 * 256;
+        out.f_hi = ((c1 < ci ? c1 : ci) + 1) * 256;   // never beyond the instantiation's capacity
+        bool started = false;
+        for (int c = c0; c <= c1; ++c)
+            if (cls[c].any) {
+                if (!started) { out.lo = cls[c].lo; started = true; }
+                out.n = cls[c].lo + cls[c].n - out.lo;
+                if (cls[c].maxT > out.maxT) out.maxT = cls[c].maxT;
+                if (cls[c].maxF > out.maxF) out.maxF = cls[c].maxF;
+            }
+    };
+    if (present == 1) { fill(g[0], first, first, first); return 1; }
+    int ng = 0;
+    if (first <= 1) { fill(g[ng], 0, 1, cls[1].any ? 1 : 0); ++ng; }
+    if (last >= 2) { fill(g[ng], 2, 6, last); g[ng].f_hi = (last + 1) * 256; ++ng; }
+    return ng;
+}
+
 template <typename QT>
-static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, const ClassRange (&cls)[7], bool grouped,
-                          const int32_t *head_idx, int n_heads, float qk_scale, float *cost, unsigned *segstate,
-                          hipStream_t st) {
-#define WT_LAUNCH_ROWMEAN(CI)                                                                                       \
-    if (cls[CI].any) {                                                                                              \
-        dim3 grid((cls[CI].maxT + 3) / 4, grouped ? cls[CI].n : n_seg);                                             \
-        hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx,      \
-                           n_heads, qk_scale, cost, segstate, grouped ? cls[CI].lo : 0);                            \
-    }
-    WT_LAUNCH_ROWMEAN(0)
-    WT_LAUNCH_ROWMEAN(1)
-    WT_LAUNCH_ROWMEAN(2)
-    WT_LAUNCH_ROWMEAN(3)
-    WT_LAUNCH_ROWMEAN(4)
-    WT_LAUNCH_ROWMEAN(5)
-    WT_LAUNCH_ROWMEAN(6)
+static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, const LaunchGroup *groups, int n_groups,
+                          bool grouped, const int32_t *head_idx, int n_heads, float qk_scale, float *cost,
+                          unsigned *segstate, hipStream_t st) {
+    for (int k = 0; k < n_groups; ++k) {
+        const LaunchGroup &g = groups[k];
+        const dim3 grid((g.maxT + 3) / 4, grouped ? g.n : n_seg);
+        const int unit0 = grouped ? g.lo : 0;
+#define WT_LAUNCH_ROWMEAN(CI)                                                                                        \
+    case CI:                                                                                                         \
+        hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, n_heads, \
+                           qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi);                                          \
+        break;
+        switch (g.ci) {
+            WT_LAUNCH_ROWMEAN(0)
+            WT_LAUNCH_ROWMEAN(1)
+            WT_LAUNCH_ROWMEAN(2)
+            WT_LAUNCH_ROWMEAN(3)
+            WT_LAUNCH_ROWMEAN(4)
+            WT_LAUNCH_ROWMEAN(5)
+            WT_LAUNCH_ROWMEAN(6)
+        }
 #undef WT_LAUNCH_ROWMEAN
+    }
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
@@ -328,21 +368,25 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     int rc = scratch(st, (size_t)n_seg * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
     ClassRange cls[7];
-    const bool grouped = class_ranges(segs_host, n_seg, cls);
+    bool grouped = class_ranges(segs_host, n_seg, cls);
+    LaunchGroup groups[2];
+    const int n_groups = plan_groups(cls, groups);
+    // the two groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
-        rc = launch_rowmean((const float *)qk, segs_dev, n_seg, cls, grouped, head_idx, n_heads, qk_scale, cost, segstate, st);
+        rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
+                            segstate, st);
     else if (qk_dtype == WT_DTYPE_F16)
-        rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, cls, grouped, head_idx, n_heads, qk_scale, cost, segstate, st);
+        rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
+                            segstate, st);
     else {
         set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
         return WT_E_BADARG;
     }
     if (rc) return rc;
     if (grouped) {
-        for (int c = 0; c < 7; ++c)
-            if (cls[c].any)
-                hipLaunchKernelGGL(colnorm_kernel, dim3((cls[c].maxF + 63) / 64, cls[c].n), dim3(64 * CN_WAVES), 0, st, cost,
-                                   segs_dev, segstate, cls[c].lo);
+        for (int k = 0; k < n_groups; ++k)
+            hipLaunchKernelGGL(colnorm_kernel, dim3((groups[k].maxF + 63) / 64, groups[k].n), dim3(64 * CN_WAVES), 0, st, cost,
+                               segs_dev, segstate, groups[k].lo);
     } else {
         hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate,
                            0);
