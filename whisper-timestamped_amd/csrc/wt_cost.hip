@@ -291,7 +291,7 @@ struct LaunchGroup {
     int lo = 0, n = 0;      // unit range when grouped
     int maxT = 0, maxF = 0, f_lo = 0, f_hi = 0;
 };
-static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2]) {
+static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2], bool &contiguous) {
     int first = -1, last = -1, present = 0;
     for (int c = 0; c < 7; ++c)
         if (cls[c].any) { if (first < 0) first = c; last = c; ++present; }
@@ -300,14 +300,18 @@ static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2]) {
         out.ci = ci;
         out.f_lo = c0 * 256;
         out.f_hi = ((c1 < ci ? c1 : ci) + 1) * 256;   // never beyond the instantiation's capacity
-        bool started = false;
+        int lo = 1 << 30, hi = 0, members = 0;
         for (int c = c0; c <= c1; ++c)
             if (cls[c].any) {
-                if (!started) { out.lo = cls[c].lo; started = true; }
-                out.n = cls[c].lo + cls[c].n - out.lo;
+                if (cls[c].lo < lo) lo = cls[c].lo;
+                if (cls[c].lo + cls[c].n > hi) hi = cls[c].lo + cls[c].n;
+                members += cls[c].n;
                 if (cls[c].maxT > out.maxT) out.maxT = cls[c].maxT;
                 if (cls[c].maxF > out.maxF) out.maxF = cls[c].maxF;
             }
+        out.lo = lo;
+        out.n = hi - lo;
+        if (out.n != members) contiguous = false;     // the group's classes are not adjacent in the unit order
     };
     if (present == 1) { fill(g[0], first, first, first); return 1; }
     int ng = 0;
@@ -370,7 +374,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     ClassRange cls[7];
     bool grouped = class_ranges(segs_host, n_seg, cls);
     LaunchGroup groups[2];
-    const int n_groups = plan_groups(cls, groups);
+    const int n_groups = plan_groups(cls, groups, grouped);
     // the two groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
