@@ -23,6 +23,11 @@ PARITY STATUS
   inputs (tests/test_oracle.py).
 * word splitting: pinned by the reference's known-answer test
   tests/test_transcribe.py:722-902 (tests/golden/split_tokens_kat.json).
+* the strategies around the alignment (hook state machine, naive re-run, confidences, post-fixers, VAD
+  back-conversion) are NOT restated here: their parity is established directly against the output of the
+  reference's own transcribe_timestamped (tests/golden/make_golden_transcribe.py ->
+  tests/golden/transcribe_cases.json), with this module standing in for the kernels in the CPU run
+  (tests/cpu_kernel_standin.py).
 """
 from __future__ import annotations
 
