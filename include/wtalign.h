@@ -88,7 +88,8 @@ int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ct
  * cost[0,0] = min(cost).  fp32 arithmetic like the reference's torch CPU ops;
  * the result, widened to double, is the matrix the reference hands to dtw.dtw.
  *   qk        : QK logits (fp32 or fp16 per qk_dtype), layout per wt_seg_desc
- *   segs_host : n_seg descriptors in host memory (launch geometry)
+ *   segs_host : n_seg descriptors in host memory (launch geometry).  Any order is correct; handing the units
+ *               over sorted by ceil(F/256) lets the library launch each group over its own units only
  *   segs_dev  : the same n_seg descriptors in device memory
  *   head_idx  : device int32[n_heads], flat head indices in the order of
  *               alignment_heads.indices().T (T.py:1545); all heads => 0..L*H-1
@@ -139,7 +140,10 @@ int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_st
  *   pcm            : device fp32 [n_chunks][n_samples]
  *   n_valid_samples: device int32[n_chunks] real samples per chunk (<= n_samples)
  *   mel_out        : device fp32 [n_chunks][n_mels][n_frames]
- *   gmax           : device fp32[n_chunks] scratch/out = per-chunk max of log10 mel */
+ *   gmax           : optional device fp32[n_chunks] out = per-chunk max of log10 mel (before the clamp)
+ * n_frames may be anything (a whole file: n_samples / 160); the log10 uses the hardware log2 (|err| < 3e-7) and
+ * the power is |X|^2 without the square root round trip of torch's abs()**2: results agree with
+ * torch.stft-based log_mel_spectrogram to 2e-4 absolute (tests/test_gpu_parity.py). */
 int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
                     int n_mels, int n_frames, float *mel_out, float *gmax, void *stream);
 
