@@ -171,3 +171,27 @@ def test_gpu_log_mel_patch_is_scoped():
             assert on is True and mod.log_mel_spectrogram is not original
             raise RuntimeError("decode failed")
     assert mod.log_mel_spectrogram is original
+
+
+def test_c_abi_argument_validation_without_a_gpu():
+    """Error behaviour of the boundary (include/wtalign.h): bad arguments are refused on the host, before any HIP
+    call, with a negative code and a message -- checked here without a GPU."""
+    from whisper_timestamped import _lib
+    L = _lib.load()
+    descs = _lib.make_descs(1)
+    descs[0]["T"], descs[0]["F"] = 10, 100
+    p = descs.ctypes.data
+    assert L.wt_cost_batch(0, 0, p, p, 1, 0, 8, 9, 1.0, 0, 0) == -1 and b"null pointer" in L.wt_last_error()
+    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 7, 1.0, p, 0) == -3 and b"medfilt_width=7" in L.wt_last_error()
+    assert L.wt_cost_batch(p, 5, p, p, 0, p, 8, 9, 1.0, p, 0) == 0                     # n_seg == 0: nothing to do
+    descs[0]["F"] = 5000
+    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 9, 1.0, p, 0) == -3 and b"unsupported shape" in L.wt_last_error()
+    assert L.wt_dtw_batch(p, p, p, 1, p, 0, 0, 0, 0, 0) == -3 and b"unsupported shape" in L.wt_last_error()
+    assert L.wt_dtw_batch(p, p, p, 1, p, p, 0, 0, 0, 0) == -1                          # path_i without path_j
+    assert L.wt_logprob_gather_batch(p, 0, 10, 4, 100, p, p, 0, p, 0) == -1            # row_stride < V
+    assert L.wt_logprob_gather_batch(p, 0, 100, 4, 100, p, p, 2, p, 0) == -1           # suppress_rows not in {0,1,n}
+    assert L.wt_logprob_gather_batch(p, 0, 100, 0, 100, p, 0, 0, p, 0) == 0
+    assert L.wt_capture_rows(p, 0, 6, 1, 1500, p, p, 2, p, 0, 16, 16, 0) == -1 and b"row=16 of 16" in L.wt_last_error()
+    assert L.wt_find_start_padding_batch(p, 1, 80, 1, p, 0) == -1
+    assert L.wt_logmel_batch(p, 1, 100, 0, p, 80, 3000, p, 0, 0) == -1                 # fewer than 201 samples
+    assert L.wt_shutdown() == 0
