@@ -107,3 +107,14 @@ def test_capture_ring_rows_match_reference_hook():
     assert view.data_ptr() == ring.buf[:, 1].data_ptr() and view.shape == (4, 3, 1500)
     gathered = ring.rows([0, 2])
     assert torch.equal(gathered[:, 1], ring.buf[:, 2])
+
+
+def test_transcribe_reusing_decoder_logits(monkeypatch):
+    """Opt-in: no second projection + filter pass per token (efficient.REUSE_DECODER_LOGITS)."""
+    from whisper_timestamped import efficient
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", True)
+    for name in ("two_windows_prompted", "decoding_limit", "language_detection", "no_trust_whisper_timestamps"):
+        case = _by_name(name)
+        got = run_case(case, device="cuda:0")
+        dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
+        _report(name + "[decoder logits reused]", dt, dc)

@@ -75,3 +75,18 @@ def test_transcribe_host_logic_equals_reference(case, monkeypatch):
 
 def is_sampled(case):
     return case["opts"].get("best_of") is not None
+
+
+EFFICIENT = [c for c in CASES if not (c["opts"].get("naive_approach") or c["opts"].get("beam_size") or c["opts"].get("best_of")
+                                      or isinstance(c["opts"].get("temperature"), (list, tuple)))]
+
+
+@pytest.mark.parametrize("case", EFFICIENT, ids=[c["name"] for c in EFFICIENT])
+def test_reusing_the_decoder_logits_gives_the_same_result(case, monkeypatch):
+    """Opt-in efficient.REUSE_DECODER_LOGITS: the filtered logits whisper's sampler leaves behind instead of a second
+    projection + filter pass per token.  Same words and times; confidences equal up to GEMM-vs-GEMV rounding."""
+    from whisper_timestamped import efficient
+    cpu_kernel_standin.install(monkeypatch)
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", True)
+    got = run_case(copy.deepcopy(case))
+    compare(got, case["expected"], time_tol=0.0, conf_tol=1e-3 + 1e-9, logprob_tol=1e-5)

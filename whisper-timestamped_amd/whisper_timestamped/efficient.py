@@ -36,6 +36,12 @@ logger = logging.getLogger("whisper_timestamped")
 RING_DTYPE = torch.float32
 # compute whisper's whole-file log-mel with the HIP front end instead of torch.stft (backend.gpu_log_mel)
 GPU_FRONT_END = True
+# Opt-in: take the step's filtered logits from the decoder itself instead of re-projecting ln's output and
+# re-applying the logit filters as the reference does (transcribe.py:871-874 duplicates, once per token, a D x V
+# GEMV and the filters whisper's sampler has just applied in place to the tensor the decoder returned).  The row is
+# read one step later, when the sampler is done with it.  Same values up to GEMM-vs-GEMV rounding of the first
+# step of a window; off by default because it relies on the backend filtering IN PLACE.
+REUSE_DECODER_LOGITS = False
 
 
 class EfficientSession:
@@ -96,6 +102,7 @@ class EfficientSession:
         self.first_segment_of_window = 0  # index_begin_30sec_chunck
         self._pad_cache = (None, None)
         self.detected_language = False
+        self.pending_logits = None
 
     # ------------------------------------------------------------------ small predicates
     def _is_sot(self, cur):
@@ -119,6 +126,7 @@ class EfficientSession:
         cur = ins[0]
         assert cur.shape[0] == 1, "Batch decoding is not supported"
         cur = cur[0].tolist()                     # the per-step host read whisper's own loop needs anyway
+        self._commit_pending_logits()             # (REUSE_DECODER_LOGITS) the previous step's row is final by now
         tk = self.tokenizer
         sot = self._is_sot(cur)
         if sot:
@@ -151,6 +159,27 @@ class EfficientSession:
         qk = outs[-1]
         assert qk is not None, "cross-attention QK is None: decode inside whisper.model.disable_sdpa()"
         self.ring.write(index, qk, self.open_rows[-1])
+
+    def hook_decoder_logits(self, layer, ins, outs):
+        """REUSE_DECODER_LOGITS: forward hook on model.decoder; outs = (1, n_q, V) fp32 logits, not yet filtered."""
+        tk = self.tokenizer
+        if self.sot_index is not None and self.no_speech_prob is None:
+            self.no_speech_prob = outs[0, self.sot_index].float().softmax(dim=-1)[tk.no_speech].item()
+        if self.language is None and self.sot_index is not None and self.model.is_multilingual:
+            lo = tk.sot + 1
+            probs = outs[0, self.sot_index, lo:lo + len(tk.all_language_tokens)].float().softmax(dim=-1)
+            self.language_probs = dict(zip(backend.whisper().tokenizer.LANGUAGES, probs.tolist()))
+        if self.has_started:
+            at_limit = self.new_whisper and self._reached_decoding_limit()
+            self.pending_logits = (outs, at_limit)    # a reference: the sampler filters outs[:, -1] in place
+
+    def _commit_pending_logits(self):
+        if self.pending_logits is None:
+            return
+        outs, at_limit = self.pending_logits
+        self.pending_logits = None
+        self.logits.append(outs[0, -1])
+        self.last_chunk_token = self.logits.argmax(-1) if at_limit else None
 
     def hook_decoder_output(self, layer, ins, outs):
         tk = self.tokenizer
@@ -460,12 +489,16 @@ class EfficientSession:
                 hooks.append(model.decoder.blocks[b].cross_attn.register_forward_hook(
                     lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
             if self.compute_word_confidence or self.no_speech_threshold is not None:
-                hooks.append(model.decoder.ln.register_forward_hook(self.hook_decoder_output))
+                if REUSE_DECODER_LOGITS:
+                    hooks.append(model.decoder.register_forward_hook(self.hook_decoder_logits))
+                else:
+                    hooks.append(model.decoder.ln.register_forward_hook(self.hook_decoder_output))
             with torch.no_grad(), backend.attention_weights_exposed(), backend.gpu_log_mel(model.device, GPU_FRONT_END):
                 transcription = model.transcribe(audio, **self.opts)
         finally:
             for h in hooks:
                 h.remove()
+        self._commit_pending_logits()
         self._may_flush()
         self.segment_tokens.pop(-1)
         return self._compile(transcription)
