@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""What do word timestamps cost on top of plain decoding?  (GPU box; whisper double, random weights, scripted tokens)
+
+Times, for one 30 s clip and a scripted ~110-token transcript on a whisper-base-shaped model:
+  plain      : the backend's own transcribe() (no hooks)
+  timestamped: this repository's transcribe() (capture ring + filtered-logit ring + HIP alignment per segment)
+  reuse      : the same with efficient.REUSE_DECODER_LOGITS (no second projection + filter pass per token)
+Prints one JSON line.  The decode loop itself is the backend's Python loop (batch 1), as with the reference.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import whisper_double as W  # noqa: E402
+from whisper_double.decoding import Script, set_script  # noqa: E402
+from golden import make_golden_transcribe as G  # noqa: E402
+
+W.install()
+import whisper_timestamped as wt  # noqa: E402
+from whisper_timestamped import efficient  # noqa: E402
+
+
+def main():
+    dev = "cuda:0"
+    model = W.build_model("base", seed=0, device=dev)
+    g = torch.Generator().manual_seed(5)
+    audio = (0.05 * torch.randn(30 * 16000, generator=g)).float()
+    ML, EOT = 50364, 50257
+    segs = [(s, [None] * n, e) for s, n, e in [(0, 20, 280), (300, 22, 600), (620, 18, 900), (920, 21, 1200), (1220, 19, 1490)]]
+    script = [G.window_script(ML, EOT, segs, "eot")]
+    n_tokens = len(script[0])
+
+    def timed(fn, reps=3):
+        best = None
+        for _ in range(reps):
+            set_script(Script(script))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            set_script(None)
+            best = dt if best is None else min(best, dt)
+        return best, out
+
+    with torch.no_grad():
+        t_plain, _ = timed(lambda: model.transcribe(audio, language="en", temperature=0.0, fp16=False))
+    t_ts, res = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    efficient.REUSE_DECODER_LOGITS = True
+    t_reuse, res2 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    efficient.REUSE_DECODER_LOGITS = False
+    words = sum(len(s.get("words", [])) for s in res["segments"])
+    same = [w["start"] for s in res["segments"] for w in s["words"]] == [w["start"] for s in res2["segments"] for w in s["words"]]
+    print(json.dumps(dict(model="whisper-base shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
+                          plain_s=round(t_plain, 4), timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
+                          overhead_pct=round(100 * (t_ts / t_plain - 1), 1),
+                          overhead_reuse_pct=round(100 * (t_reuse / t_plain - 1), 1),
+                          ms_per_token_plain=round(1e3 * t_plain / n_tokens, 3), same_word_times=same)))
+
+
+if __name__ == "__main__":
+    main()
