@@ -81,6 +81,16 @@ int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ct
                     const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row,
                     void *stream);
 
+/* The same rows computed from the projections instead of observed: qk[h, r, f] = sum_d (q[r, h*hd+d] * s) *
+ * (k[f, h*hd+d] * s), s = hd^-0.25, for n_sel heads and n_rows query rows, written to ring[slots[i]][row0 + r][:].
+ * Lets the backend keep its fused attention (the reference must run every attention module unfused, inside
+ * whisper.model.disable_sdpa(), just to read these rows: T.py:49-61, 903).
+ *   q : device [n_rows][d_model]   (cross_attn.query output rows; dtype f32/f16)
+ *   k : device [n_ctx][d_model]    (cross_attn.key output of the window)                                       */
+int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int d_model, int head_dim, float scale,
+               const int32_t *heads, const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows,
+               int64_t row0, void *stream);
+
 /* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
  * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,
  * softmax over the F-frame window, mean over heads, divide by the per-frame L2

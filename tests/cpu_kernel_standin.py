@@ -15,6 +15,7 @@ from oracle import align_ref as O
 def install(monkeypatch):
     from whisper_timestamped import _lib, alignment, capture, efficient
     monkeypatch.setattr(efficient, "GPU_FRONT_END", False)      # the backend's own torch.stft on the CPU
+    monkeypatch.setattr(efficient, "FUSED_ATTENTION", False)    # qk observed on the unfused path, as in the reference
 
     monkeypatch.setattr(_lib, "require_gpu", lambda device, what="": None)
     monkeypatch.setattr(_lib, "_need_cuda", lambda t, name: None)

@@ -118,3 +118,40 @@ def test_transcribe_reusing_decoder_logits(monkeypatch):
         got = run_case(case, device="cuda:0")
         dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
         _report(name + "[decoder logits reused]", dt, dc)
+
+
+def test_qk_rows_from_projections_match_the_observed_qk():
+    """wt_qk_rows == the rows hook_attention_weights would read from MultiHeadAttention's unfused path
+    (whisper/model.py qkv_attention: (q * scale) @ (k * scale)^T, .float())."""
+    from whisper_timestamped.capture import QKCaptureRing
+    g = torch.Generator().manual_seed(11)
+    H, hd, n_ctx = 6, 64, 1500
+    D = H * hd
+    pairs = [(0, 1), (1, 0), (1, 5), (2, 3)]
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float16, 2e-2)):
+        ring = QKCaptureRing("cuda:0", pairs, n_hooked_layers=3, n_heads=H, n_ctx=n_ctx, capacity=32)
+        want = {}
+        for layer in range(3):
+            q = (torch.randn((1, 7, D), generator=g) * 0.7).to(dtype).cuda()
+            k = (torch.randn((1, n_ctx, D), generator=g) * 0.7).to(dtype).cuda()
+            ring.write_from_projections(layer, q, k, row0=3, n_rows=1)           # efficient strategy: last query row
+            ring.write_from_projections(layer, q, k, row0=10, n_rows=7)          # naive strategy: every query row
+            scale = hd ** -0.25
+            qh = (q * scale).view(1, 7, H, hd).permute(0, 2, 1, 3)
+            kh = (k * scale).view(1, n_ctx, H, hd).permute(0, 2, 1, 3)
+            want[layer] = (qh @ kh.transpose(-1, -2)).float()[0]                 # (H, 7, n_ctx)
+        torch.cuda.synchronize()
+        for slot, (l, h) in enumerate(pairs):
+            assert (ring.buf[slot, 3] - want[l][h, -1]).abs().max().item() <= tol
+            assert (ring.buf[slot, 10:17] - want[l][h]).abs().max().item() <= tol
+
+
+def test_transcribe_with_the_reference_attention_path(monkeypatch):
+    """efficient.FUSED_ATTENTION = False: qk observed on the backend's unfused path (disable_sdpa), as the reference does."""
+    from whisper_timestamped import efficient
+    monkeypatch.setattr(efficient, "FUSED_ATTENTION", False)
+    for name in ("one_window_two_segments", "no_trust_whisper_timestamps", "naive_greedy", "naive_no_trust"):
+        case = _by_name(name)
+        got = run_case(case, device="cuda:0")
+        dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
+        _report(name + "[unfused attention]", dt, dc)

@@ -85,6 +85,8 @@ int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_
 int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
 int capture_rows(const void *, int, int, int, int, const int32_t *, const int32_t *, int, void *, int, int64_t, int64_t,
                  hipStream_t);
+int qk_rows(const void *, const void *, int, int, int, int, int, float, const int32_t *, const int32_t *, int, void *, int,
+            int64_t, int64_t, hipStream_t);
 
 }  // namespace wt
 
@@ -113,6 +115,13 @@ int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ct
                     int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row, void *stream) {
     return wt::capture_rows(qk, qk_dtype, n_heads, n_q, n_ctx, heads, slots, n_sel, ring, ring_dtype, ring_rows, row,
                             (hipStream_t)stream);
+}
+
+int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int d_model, int head_dim, float scale,
+               const int32_t *heads, const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows,
+               int64_t row0, void *stream) {
+    return wt::qk_rows(q, k, dtype, n_rows, n_ctx, d_model, head_dim, scale, heads, slots, n_sel, ring, ring_dtype, ring_rows,
+                       row0, (hipStream_t)stream);
 }
 
 int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,

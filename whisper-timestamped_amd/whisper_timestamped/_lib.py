@@ -27,7 +27,7 @@ SEG_DTYPE = np.dtype([
 assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
-           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows"]
+           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows"]
 
 
 class WtError(RuntimeError):
@@ -57,6 +57,7 @@ def load():
     L.wt_logprob_gather_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, i32, vp, vp]
     L.wt_logmel_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.wt_capture_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, vp]
+    L.wt_qk_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, i64, i64, vp]
     for n in EXPORTS[3:]:
         getattr(L, n).restype = i32
     _lib = L

@@ -29,12 +29,13 @@ def ge_20230306() -> bool:   # segment tokens include the timestamp tokens, mode
 
 
 @contextmanager
-def attention_weights_exposed():
+def attention_weights_exposed(enabled=True):
     """openai-whisper >= 20240930 returns qk=None from the fused SDPA path; the
-    reference wraps decoding in whisper.model.disable_sdpa() (transcribe.py:49-58,900)."""
+    reference wraps decoding in whisper.model.disable_sdpa() (transcribe.py:49-58,900).
+    ``enabled=False``: leave the backend on its fused path (the QK rows are then computed by wt_qk_rows)."""
     w = whisper()
     ctx = getattr(getattr(w, "model", None), "disable_sdpa", None)
-    if ctx is None or whisper_version() < "20240930":
+    if not enabled or ctx is None or whisper_version() < "20240930":
         yield
     else:
         with ctx():

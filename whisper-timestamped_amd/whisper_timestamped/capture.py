@@ -69,6 +69,30 @@ class QKCaptureRing:
                                        self.capacity, int(row), _lib._stream())
         _lib._check(rc, "wt_capture_rows")
 
+    def write_from_projections(self, layer_index: int, q: torch.Tensor, k: torch.Tensor, row0: int, n_rows: int = 1):
+        """The same rows from the cross-attention projections (wt_qk_rows): q = cross_attn.query(x) (1, n_q, D), of
+        which the LAST n_rows query rows are used; k = cross_attn.key(xa) (1, n_ctx, D).  The backend can then stay
+        on its fused attention path (no whisper.model.disable_sdpa())."""
+        _lib._need_cuda(q, "q")
+        heads = self._heads[layer_index]
+        if heads.numel() == 0:
+            return
+        assert q.dim() == 3 and k.dim() == 3 and q.shape[0] == 1 and k.shape[0] == 1 and k.shape[1] == self.n_ctx, (q.shape, k.shape)
+        assert q.dtype == k.dtype and q.shape[2] == k.shape[2]
+        d_model = q.shape[2]
+        head_dim = d_model // self.n_heads
+        qr = q[0, q.shape[1] - n_rows:]
+        kr = k[0]
+        if not qr.is_contiguous():
+            qr = qr.contiguous()
+        if not kr.is_contiguous():
+            kr = kr.contiguous()
+        dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[q.dtype]
+        rc = self._lib.wt_qk_rows(qr.data_ptr(), kr.data_ptr(), dt, n_rows, self.n_ctx, d_model, head_dim,
+                                  float(head_dim) ** -0.25, heads.data_ptr(), self._slots[layer_index].data_ptr(),
+                                  heads.numel(), self.buf.data_ptr(), self._dt, self.capacity, int(row0), _lib._stream())
+        _lib._check(rc, "wt_qk_rows")
+
     def rows(self, rows) -> torch.Tensor:
         """(A_sel, len(rows), n_ctx): a strided VIEW when the rows are consecutive, else a device gather."""
         rows = list(rows)

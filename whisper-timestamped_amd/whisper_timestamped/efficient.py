@@ -42,6 +42,11 @@ GPU_FRONT_END = True
 # read one step later, when the sampler is done with it.  Same values up to GEMM-vs-GEMV rounding of the first
 # step of a window; off by default because it relies on the backend filtering IN PLACE.
 REUSE_DECODER_LOGITS = False
+# Compute the alignment heads' QK rows from cross_attn.query / cross_attn.key outputs (wt_qk_rows) and let the backend
+# keep its fused attention.  The reference reads qk from MultiHeadAttention's second output, which only exists on the
+# unfused path: it runs EVERY attention module of the model (encoder included) unfused, inside
+# whisper.model.disable_sdpa().  False = exactly that (the reference's attention arithmetic for the whole model).
+FUSED_ATTENTION = True
 
 
 class EfficientSession:
@@ -103,6 +108,8 @@ class EfficientSession:
         self._pad_cache = (None, None)
         self.detected_language = False
         self.pending_logits = None
+        self._q = [None] * len(self.hooked_blocks)
+        self._k = [None] * len(self.hooked_blocks)
 
     # ------------------------------------------------------------------ small predicates
     def _is_sot(self, cur):
@@ -159,6 +166,10 @@ class EfficientSession:
         qk = outs[-1]
         assert qk is not None, "cross-attention QK is None: decode inside whisper.model.disable_sdpa()"
         self.ring.write(index, qk, self.open_rows[-1])
+
+    def hook_cross_attention_fused(self, index, layer, ins, outs):
+        if self.has_started:
+            self.ring.write_from_projections(index, self._q[index], self._k[index], self.open_rows[-1])
 
     def hook_decoder_logits(self, layer, ins, outs):
         """REUSE_DECODER_LOGITS: forward hook on model.decoder; outs = (1, n_q, V) fp32 logits, not yet filtered."""
@@ -486,14 +497,22 @@ class EfficientSession:
                  model.decoder.token_embedding.register_forward_hook(self.hook_tokens)]
         try:
             for j, b in enumerate(self.hooked_blocks):
-                hooks.append(model.decoder.blocks[b].cross_attn.register_forward_hook(
-                    lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
+                ca = model.decoder.blocks[b].cross_attn
+                if FUSED_ATTENTION:
+                    hooks.append(ca.query.register_forward_hook(lambda m, i, o, index=j: self._q.__setitem__(index, o)))
+                    hooks.append(ca.key.register_forward_hook(lambda m, i, o, index=j: self._k.__setitem__(index, o)))
+                    hooks.append(ca.register_forward_hook(
+                        lambda layer, ins, outs, index=j: self.hook_cross_attention_fused(index, layer, ins, outs)))
+                else:
+                    hooks.append(ca.register_forward_hook(
+                        lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
             if self.compute_word_confidence or self.no_speech_threshold is not None:
                 if REUSE_DECODER_LOGITS:
                     hooks.append(model.decoder.register_forward_hook(self.hook_decoder_logits))
                 else:
                     hooks.append(model.decoder.ln.register_forward_hook(self.hook_decoder_output))
-            with torch.no_grad(), backend.attention_weights_exposed(), backend.gpu_log_mel(model.device, GPU_FRONT_END):
+            with torch.no_grad(), backend.attention_weights_exposed(not FUSED_ATTENTION), \
+                    backend.gpu_log_mel(model.device, GPU_FRONT_END):
                 transcription = model.transcribe(audio, **self.opts)
         finally:
             for h in hooks:

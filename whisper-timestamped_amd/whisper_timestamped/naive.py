@@ -97,8 +97,8 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
         hooks.append(model.decoder.ln.register_forward_hook(hook_language))
     try:
         model.alignment_heads = alignment_heads
-        from .efficient import GPU_FRONT_END
-        with torch.no_grad(), backend.attention_weights_exposed(), backend.gpu_log_mel(model.device, GPU_FRONT_END):
+        from .efficient import FUSED_ATTENTION as _fused, GPU_FRONT_END
+        with torch.no_grad(), backend.attention_weights_exposed(not _fused), backend.gpu_log_mel(model.device, GPU_FRONT_END):
             transcription = model.transcribe(audio, **whisper_options)
     finally:
         for h in hooks:
@@ -129,6 +129,11 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
     _lib.require_gpu(dev)
     pairs = head_pairs(alignment_heads)
     captured = [None] * top
+    from .efficient import FUSED_ATTENTION
+    from .capture import QKCaptureRing
+    fused_q, fused_k = [None] * top, [None] * top
+    ring = QKCaptureRing(dev, pairs, top, model.dims.n_text_head, n_ctx=model.dims.n_audio_ctx,
+                         capacity=model.dims.n_text_ctx) if FUSED_ATTENTION else None
 
     hooks = []
     try:
@@ -136,8 +141,12 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
         for i, block in enumerate(model.decoder.blocks):
             if i < n_blocks - top:
                 continue
-            hooks.append(block.cross_attn.register_forward_hook(
-                lambda layer, ins, outs, index=j: captured.__setitem__(index, outs[1])))
+            if FUSED_ATTENTION:     # q / K of the projections: the rows are computed by wt_qk_rows after the forward
+                hooks.append(block.cross_attn.query.register_forward_hook(lambda m, i, o, index=j: fused_q.__setitem__(index, o)))
+                hooks.append(block.cross_attn.key.register_forward_hook(lambda m, i, o, index=j: fused_k.__setitem__(index, o)))
+            else:
+                hooks.append(block.cross_attn.register_forward_hook(
+                    lambda layer, ins, outs, index=j: captured.__setitem__(index, outs[1])))
             j += 1
 
         window_tokens, token_to_segment = [], []
@@ -224,13 +233,19 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
             tokens = [*sot_sequence, tokenizer.timestamp_begin] + tokens
             i_start = len(sot_sequence)
 
-            with torch.no_grad(), backend.attention_weights_exposed():
+            with torch.no_grad(), backend.attention_weights_exposed(not FUSED_ATTENTION):
                 logits = model(mfcc, torch.tensor(tokens, dtype=torch.int32, device=dev).unsqueeze(0))
             logits = logits[0]                                       # (T_all, V), teacher forced; NO logit filters (:1245)
 
             end_token = tokenizer.timestamp_begin + round(min(N_FRAMES * HOP_LENGTH, end_sample - start_sample) // AUDIO_SAMPLES_PER_TOKEN)
             tokens = tokens[i_start:] + [end_token]
-            qk_sel = _select_heads(captured, pairs, i_start - 1)
+            if FUSED_ATTENTION:
+                n_q = fused_q[0].shape[1]
+                for index in range(top):
+                    ring.write_from_projections(index, fused_q[index], fused_k[index], 0, n_rows=n_q)
+                qk_sel = ring.buf[:, i_start - 1:n_q]
+            else:
+                qk_sel = _select_heads(captured, pairs, i_start - 1)
 
             unit = prepare_unit(tokens, None, tokenizer, use_space=use_space, mfcc=mfcc,
                                 refine_whisper_precision_nframes=refine_whisper_precision_nframes,
