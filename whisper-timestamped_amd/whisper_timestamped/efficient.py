@@ -190,6 +190,11 @@ class EfficientSession:
         outs, at_limit = self.pending_logits
         self.pending_logits = None
         self.logits.append(outs[0, -1])
+        if len(self.logits) == 1 and self.tokenizer.no_timestamps is not None:
+            # once per window: the row must carry the sampler's in-place filtering (<|notimestamps|> is always -inf)
+            if not bool(torch.isinf(self.logits.buf[0, self.tokenizer.no_timestamps])):
+                raise RuntimeError("REUSE_DECODER_LOGITS: this backend does not filter the decoder's logits in place; "
+                                   "set whisper_timestamped.efficient.REUSE_DECODER_LOGITS = False")
         self.last_chunk_token = self.logits.argmax(-1) if at_limit else None
 
     def hook_decoder_output(self, layer, ins, outs):
