@@ -3,7 +3,9 @@
 
 Times, for one 30 s clip and a scripted ~110-token transcript on a whisper-base-shaped model:
   plain      : the backend's own transcribe() (no hooks)
-  timestamped: this repository's transcribe() (capture ring + filtered-logit ring + HIP alignment per segment)
+  unfused    : this repository's transcribe() with efficient.FUSED_ATTENTION = False (qk observed inside
+               whisper.model.disable_sdpa(), the only way the reference can get it)
+  timestamped: this repository's transcribe() (wt_qk_rows + filtered-logit ring + HIP alignment per segment)
   reuse      : the same with efficient.REUSE_DECODER_LOGITS (no second projection + filter pass per token)
 Prints one JSON line.  The decode loop itself is the backend's Python loop (batch 1), as with the reference.
 """
@@ -52,14 +54,20 @@ def main():
 
     with torch.no_grad():
         t_plain, _ = timed(lambda: model.transcribe(audio, language="en", temperature=0.0, fp16=False))
+    efficient.FUSED_ATTENTION = False             # the reference's way: every attention module unfused, qk observed
+    t_unfused, res0 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    efficient.FUSED_ATTENTION = True
     t_ts, res = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
     efficient.REUSE_DECODER_LOGITS = True
     t_reuse, res2 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
     efficient.REUSE_DECODER_LOGITS = False
     words = sum(len(s.get("words", [])) for s in res["segments"])
-    same = [w["start"] for s in res["segments"] for w in s["words"]] == [w["start"] for s in res2["segments"] for w in s["words"]]
+    starts = lambda r: [(w["start"], w["end"]) for s in r["segments"] for w in s["words"]]  # noqa: E731
+    same = starts(res) == starts(res2) == starts(res0)
     print(json.dumps(dict(model="whisper-base shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
-                          plain_s=round(t_plain, 4), timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
+                          plain_s=round(t_plain, 4), timestamped_unfused_attention_s=round(t_unfused, 4),
+                          timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
+                          overhead_unfused_attention_pct=round(100 * (t_unfused / t_plain - 1), 1),
                           overhead_pct=round(100 * (t_ts / t_plain - 1), 1),
                           overhead_reuse_pct=round(100 * (t_reuse / t_plain - 1), 1),
                           ms_per_token_plain=round(1e3 * t_plain / n_tokens, 3), same_word_times=same)))
