@@ -157,6 +157,11 @@ def case_list():
                   # (beam search is forced at the RESULT level: explicit ids only, i.e. odd seeds)
                   script=[window_script(ML, EOT_ML, [seg(41, 0, 6, 400), seg(29, 420, 7, 1100)], "pair"),
                           window_script(ML, EOT_ML, [seg(43, 12, 6, 380)], "eot")]))
+    # BASELINE config 3: whisper-small multilingual, beam_size=5 (two-pass path).  The model carries no alignment_heads
+    # attribute here, so the heads come from the parameter-count table (10 heads in layers 5..10).
+    C.append(dict(name="small_beam5_table_heads", model="small", drop_alignment_heads=True, audio_s=14.0, audio_seed=24,
+                  opts=dict(language="en", beam_size=5),
+                  script=[window_script(ML, EOT_ML, [seg(61, 8, 7, 300), seg(63, 310, 6, 640)], "eot")]))
     C.append(dict(name="naive_no_trust", model="tiny", audio_s=13.0, audio_seed=16,
                   opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False,
                             include_punctuation_in_confidence=True),
@@ -175,6 +180,8 @@ def build_case(c, device="cpu"):
     import whisper_double as W
     from whisper_double.decoding import Script
     model = W.build_model(c["model"], seed=c.get("model_seed", 0), device=device)
+    if c.get("drop_alignment_heads"):
+        del model.alignment_heads
     g = torch.Generator().manual_seed(1000 + c["audio_seed"])
     n = int(round(c["audio_s"] * 16000))
     t = torch.arange(n) / 16000.0
