@@ -148,6 +148,11 @@ def case_list():
     C.append(dict(name="language_detection_no_trust", model="tiny", audio_s=9.0, audio_seed=22,
                   opts=dict(language=None, trust_whisper_timestamps=False),
                   script=[window_script(ML, EOT_ML, [seg(50, 15, 7, 200), seg(52, 210, 6, 430)], "eot")]))
+    # large-v3's front end and vocabulary on a tiny-sized model: 128 mel bins, 100 languages, timestamps start at 50365
+    C.append(dict(name="v3_like_128_mels", model="tiny-v3", audio_s=33.0, audio_seed=25,
+                  opts=dict(language="en"),
+                  script=[window_script(ML + 1, EOT_ML, [seg(64, 6, 8, 400), seg(65, 420, 7, 900)], "pair"),
+                          window_script(ML + 1, EOT_ML, [seg(66, 10, 6, 300)], "eot")]))
     # ---- naive strategy (transcribe, then teacher-forced re-run) -------------------------------------
     C.append(dict(name="naive_greedy", model="tiny", audio_s=12.0, audio_seed=14,
                   opts=dict(language="en", naive_approach=True),

@@ -224,6 +224,8 @@ class Whisper(nn.Module):
 _DIMS = {  # name: (n_mels, audio_state, audio_head, audio_layer, text_state, text_head, text_layer)
     "tiny": (80, 384, 6, 4, 384, 6, 4), "base": (80, 512, 8, 6, 512, 8, 6), "small": (80, 768, 12, 12, 768, 12, 12),
     "medium": (80, 1024, 16, 24, 1024, 16, 24), "large-v3": (128, 1280, 20, 32, 1280, 20, 32),
+    # tiny-sized model with large-v3's front end and vocabulary (128 mels, 100 languages, specials shifted by one)
+    "tiny-v3": (128, 384, 6, 4, 384, 6, 4),
 }
 
 
@@ -240,7 +242,7 @@ def build_model(name: str = "tiny", seed: int = 0, device="cpu", text_layers=Non
     english = name.endswith(".en")
     base = name[:-3] if english else name
     m, a_s, a_h, a_l, t_s, t_h, t_l = _DIMS[base]
-    n_vocab = 51864 if english else (51866 if base == "large-v3" else 51865)
+    n_vocab = 51864 if english else (51866 if base in ("large-v3", "tiny-v3") else 51865)
     dims = ModelDimensions(m, 1500, a_s, a_h, audio_layers or a_l, n_vocab, 448, t_s, t_h, text_layers or t_l)
     g = torch.Generator().manual_seed(seed)
     model = Whisper(dims)
