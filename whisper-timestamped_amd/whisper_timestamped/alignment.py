@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .words import (AUDIO_TIME_PER_TOKEN, N_AUDIO_CTX, _punctuation, frame_window, split_tokens_on_spaces,
+from .words import (AUDIO_TIME_PER_TOKEN, _punctuation, frame_window, split_tokens_on_spaces,
                     split_tokens_on_unicode, trailing_punctuation_counts, words_from_jumps)
 
 logger = logging.getLogger("whisper_timestamped")
