@@ -148,6 +148,15 @@ def case_list():
     C.append(dict(name="language_detection_no_trust", model="tiny", audio_s=9.0, audio_seed=22,
                   opts=dict(language=None, trust_whisper_timestamps=False),
                   script=[window_script(ML, EOT_ML, [seg(50, 15, 7, 200), seg(52, 210, 6, 430)], "eot")]))
+    C.append(dict(name="empty_first_window", model="tiny", audio_s=44.0, audio_seed=26,
+                  opts=dict(language="en"),
+                  script=[[ML + 10, EOT_ML],
+                          window_script(ML, EOT_ML, [seg(67, 12, 7, 300), seg(68, 320, 8, 690)], "eot")]))
+    C.append(dict(name="three_windows_single_segment_window", model="tiny", audio_s=75.0, audio_seed=27,
+                  opts=dict(language="en", refine_whisper_precision=1.0, min_word_duration=0.1, remove_punctuation_from_words=True),
+                  script=[window_script(ML, EOT_ML, [seg(69, 0, 9, 800)], "eot"),
+                          window_script(ML, EOT_ML, [seg(70, 5, 6, 400), seg(71, 410, 7, 1000), seg(72, 1010, 5, 1450)], "pair"),
+                          window_script(ML, EOT_ML, [seg(73, 30, 8, 600)], "noend")]))
     # large-v3's front end and vocabulary on a tiny-sized model: 128 mel bins, 100 languages, timestamps start at 50365
     C.append(dict(name="v3_like_128_mels", model="tiny-v3", audio_s=33.0, audio_seed=25,
                   opts=dict(language="en"),
