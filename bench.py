@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as ONE captured HIP graph (fixed shapes); stage times then come from an eager "
+                         "pass BEFORE the timed region (events cannot be read back from inside a graph)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: result records of this many steps travel to rank 0 in one RCCL gather")
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel"],
@@ -369,6 +372,20 @@ def main():
         full_step()
     torch.cuda.synchronize()
 
+    graph = None
+    if args.graph:
+        assert args.overlap == "none" and gather_buf is None, "--graph: single stream, single rank"
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):                 # the library's scratch arenas are per stream: create them
+            run_step(w, None, None)                  # (hipMalloc) before the capture, not inside it
+        cap.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            run_step(w, None, None)
+        graph.replay()
+        torch.cuda.synchronize()
+
     def make_events():
         if args.overlap != "none":
             return {st: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for st in STAGES}
@@ -381,8 +398,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        full_step(evs[k])
+    if graph is not None:
+        for k in range(args.steps):                  # eager pass for the per-stage breakdown (NOT timed below)
+            full_step(evs[k])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            graph.replay()
+    else:
+        for k in range(args.steps):
+            full_step(evs[k])
     if gather_buf is not None:
         gather_buf.drain()
     torch.cuda.synchronize()
@@ -427,6 +452,7 @@ def main():
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2}[args.overlap],
+                       "hip_graph": bool(args.graph),
                        "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
