@@ -110,39 +110,17 @@ def load_model(name, device=None, backend="openai-whisper", download_root=None, 
 
 
 def transcribe_timestamped(
-    model,
-    audio,
-    language=None,
-    task="transcribe",
-    remove_punctuation_from_words=False,
-    compute_word_confidence=True,
-    include_punctuation_in_confidence=False,
-    refine_whisper_precision=0.5,
-    min_word_duration=0.02,
-    plot_word_alignment=False,
-    word_alignment_most_top_layers=None,
-    remove_empty_words=False,
-    use_backend_timestamps=False,
-    seed=1234,
-    vad=False,
-    detect_disfluencies=False,
-    trust_whisper_timestamps=True,
-    naive_approach=False,
-    temperature=0.0,
-    best_of=None,
-    beam_size=None,
-    patience=None,
-    length_penalty=None,
-    compression_ratio_threshold=2.4,
-    logprob_threshold=-1.0,
-    no_speech_threshold=0.6,
-    fp16=None,
-    condition_on_previous_text=True,
-    initial_prompt=None,
-    suppress_tokens="-1",
-    sample_len=None,
-    verbose=False,
-):
+        model, audio, language=None, task="transcribe",
+        # word-alignment options
+        remove_punctuation_from_words=False, compute_word_confidence=True, include_punctuation_in_confidence=False,
+        refine_whisper_precision=0.5, min_word_duration=0.02, plot_word_alignment=False,
+        word_alignment_most_top_layers=None, remove_empty_words=False, use_backend_timestamps=False,
+        # reproducibility, pre-processing, strategy
+        seed=1234, vad=False, detect_disfluencies=False, trust_whisper_timestamps=True, naive_approach=False,
+        # decoding options handed to the backend
+        temperature=0.0, best_of=None, beam_size=None, patience=None, length_penalty=None,
+        compression_ratio_threshold=2.4, logprob_threshold=-1.0, no_speech_threshold=0.6, fp16=None,
+        condition_on_previous_text=True, initial_prompt=None, suppress_tokens="-1", sample_len=None, verbose=False):
     """Transcribe ``audio`` with ``model`` and add word timestamps / confidences.
 
     Arguments, defaults and the returned dictionary are those of the reference
@@ -185,15 +163,10 @@ def transcribe_timestamped(
         word_alignment_most_top_layers = 6
 
     alignment_options = dict(
-        remove_punctuation_from_words=remove_punctuation_from_words,
-        compute_word_confidence=compute_word_confidence,
-        include_punctuation_in_confidence=include_punctuation_in_confidence,
-        detect_disfluencies=detect_disfluencies,
-        refine_whisper_precision_nframes=refine_nframes,
-        plot_word_alignment=plot_word_alignment,
-        word_alignment_most_top_layers=word_alignment_most_top_layers,
-        alignment_heads=alignment_heads,
-    )
+        remove_punctuation_from_words=remove_punctuation_from_words, compute_word_confidence=compute_word_confidence,
+        include_punctuation_in_confidence=include_punctuation_in_confidence, detect_disfluencies=detect_disfluencies,
+        refine_whisper_precision_nframes=refine_nframes, plot_word_alignment=plot_word_alignment,
+        word_alignment_most_top_layers=word_alignment_most_top_layers, alignment_heads=alignment_heads)
     whisper_options = dict(
         language=language, task=task, fp16=fp16, temperature=temperature, best_of=best_of, beam_size=beam_size,
         patience=patience, length_penalty=length_penalty, condition_on_previous_text=condition_on_previous_text,
