@@ -195,3 +195,24 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.wt_find_start_padding_batch(p, 1, 80, 1, p, 0) == -1
     assert L.wt_logmel_batch(p, 1, 100, 0, p, 80, 3000, p, 0, 0) == -1                 # fewer than 201 samples
     assert L.wt_shutdown() == 0
+
+
+def test_transcribe_signature_is_the_reference_one():
+    """Positional order and defaults of transcribe_timestamped (reference transcribe.py:79-120)."""
+    import inspect
+    import whisper_timestamped as wt
+    expected = [("model", inspect._empty), ("audio", inspect._empty), ("language", None), ("task", "transcribe"),
+                ("remove_punctuation_from_words", False), ("compute_word_confidence", True),
+                ("include_punctuation_in_confidence", False), ("refine_whisper_precision", 0.5), ("min_word_duration", 0.02),
+                ("plot_word_alignment", False), ("word_alignment_most_top_layers", None), ("remove_empty_words", False),
+                ("use_backend_timestamps", False), ("seed", 1234), ("vad", False), ("detect_disfluencies", False),
+                ("trust_whisper_timestamps", True), ("naive_approach", False), ("temperature", 0.0), ("best_of", None),
+                ("beam_size", None), ("patience", None), ("length_penalty", None), ("compression_ratio_threshold", 2.4),
+                ("logprob_threshold", -1.0), ("no_speech_threshold", 0.6), ("fp16", None),
+                ("condition_on_previous_text", True), ("initial_prompt", None), ("suppress_tokens", "-1"),
+                ("sample_len", None), ("verbose", False)]
+    got = [(n, p.default) for n, p in inspect.signature(wt.transcribe_timestamped).parameters.items()]
+    assert got == expected
+    got = [(n, p.default) for n, p in inspect.signature(wt.load_model).parameters.items()]
+    assert got == [("name", inspect._empty), ("device", None), ("backend", "openai-whisper"), ("download_root", None),
+                   ("in_memory", False)]
