@@ -31,7 +31,8 @@ from whisper_timestamped import efficient  # noqa: E402
 
 def main():
     dev = "cuda:0"
-    model = W.build_model("base", seed=0, device=dev)
+    name = sys.argv[1] if len(sys.argv) > 1 else "base"
+    model = W.build_model(name, seed=0, device=dev)
     g = torch.Generator().manual_seed(5)
     audio = (0.05 * torch.randn(30 * 16000, generator=g)).float()
     ML, EOT = 50364, 50257
@@ -64,7 +65,7 @@ def main():
     words = sum(len(s.get("words", [])) for s in res["segments"])
     starts = lambda r: [(w["start"], w["end"]) for s in r["segments"] for w in s["words"]]  # noqa: E731
     same = starts(res) == starts(res2) == starts(res0)
-    print(json.dumps(dict(model="whisper-base shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
+    print(json.dumps(dict(model=f"whisper-{name} shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
                           plain_s=round(t_plain, 4), timestamped_unfused_attention_s=round(t_unfused, 4),
                           timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
                           overhead_unfused_attention_pct=round(100 * (t_unfused / t_plain - 1), 1),
