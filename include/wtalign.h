@@ -61,7 +61,8 @@ typedef struct wt_seg_desc {
     int32_t T;            /* tokens incl. the start/end timestamp tokens (T.py:1514)         */
     int32_t F;            /* end_token - start_token after T.py:1484-1489                    */
     int32_t start_token;  /* first absolute frame of the window (T.py:1540)                  */
-    int32_t pad_from;     /* max_duration of T.py:1554-1565 when the mask applies, else -1.
+    int32_t pad_from;     /* max_duration of T.py:1554-1565 when the mask applies, else -1 (0 is treated
+                             like -1: the reference tests `if max_duration:`).
                              NB (reference quirk, reproduced): an ABSOLUTE frame index used
                              as a column index RELATIVE to start_token.                      */
 } wt_seg_desc;

@@ -34,7 +34,7 @@ def main(rounds=10):
         qs = [synth.synth_qk(1000 * seed + k, 24, t, lo=s, hi=e) for k, (t, s, e) in enumerate(shapes)]
         if half:
             qs = [q.astype(np.float16).astype(np.float32) for q in qs]
-        pads = [(-1 if rng.rand() < 0.6 else int(rng.randint(0, e - s))) for _, s, e in shapes]
+        pads = [(-1 if rng.rand() < 0.6 else int(rng.randint(0, e - s))) for _, s, e in shapes]   # 0 == no mask
         got = T.run_cost(qs, heads, [(s, e) for _, s, e in shapes], pads, dtype=torch.float16 if half else torch.float32)
         for q, (t, s, e), p, g in zip(qs, shapes, pads, got):
             ref = T.oracle_cost(q, heads, (s, e), p)

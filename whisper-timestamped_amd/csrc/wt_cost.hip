@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int f = blockIdx.x * 64 + lane;
     const bool valid = f < F;
-    const bool masked_col = d.pad_from >= 0 && f >= d.pad_from;
+    const bool masked_col = d.pad_from > 0 && f >= d.pad_from;  // 0 = no mask, like the reference's `if max_duration:`
     float *base = cost + d.cost_offset + (valid ? f : 0);
 
     float v[CN_ROWS];
