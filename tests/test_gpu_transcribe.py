@@ -155,3 +155,15 @@ def test_transcribe_with_the_reference_attention_path(monkeypatch):
         got = run_case(case, device="cuda:0")
         dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
         _report(name + "[unfused attention]", dt, dc)
+
+
+def test_islands_job_matches_reference_per_island():
+    """BASELINE config 4's shape (long recording, speech islands as the sharding unit) on one GPU: every island must
+    equal the reference's transcribe() of that crop (tests/golden/islands_job.json); the 2-rank path is covered on
+    the CPU in tests/test_sharding_gloo.py with the same golden."""
+    from test_sharding_gloo import _check_islands_result, _islands_job, _run_islands_job
+    job = _islands_job()
+    result, seen = _run_islands_job(None, job, None, device="cuda:0")
+    assert seen == [0, 1, 2, 3]
+    dt, dc = _check_islands_result(result, job, time_tol=0.02, conf_tol=1e-3 + 1e-4)
+    _report("islands_job", dt, dc)

@@ -117,3 +117,103 @@ def test_partition_is_balanced_and_deterministic():
         assert sorted(i for p in parts for i in p) == list(range(200))
         assert max(loads) - min(loads) <= max(costs), (world, loads)      # LPT bound
         assert parts == partition_units(costs, world)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Long-form job sharded by speech island: every island must come out as the REFERENCE's own transcribe() of that crop
+# (tests/golden/islands_job.json, written by tests/golden/make_golden_islands.py), for 1 and 2 ranks.
+# ----------------------------------------------------------------------------------------------------------------------
+def _islands_job():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "islands_job.json"), encoding="utf-8"))
+
+
+def _run_islands_job(dist, job, patch, device="cpu"):
+    import cpu_kernel_standin
+    import whisper_double as W
+    from golden import make_golden_transcribe as G
+    from whisper_double.decoding import Script, set_script
+    if patch is not None:
+        cpu_kernel_standin.install(patch)
+    W.install()
+    from whisper_timestamped.sharding import transcribe_islands
+    model, audio, _ = G.build_case(dict(job, script=None), device=device)
+    rank = 0 if dist is None else dist.get_rank()
+    if rank != 0:                      # rank 0 owns the truth: the others start from garbage weights and no audio
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+        audio = None
+    seen = []
+
+    def on_island(i):
+        seen.append(i)
+        set_script(Script(job["recorded"][i]))       # replay what the reference's decoder sampled on this island
+    try:
+        result = transcribe_islands(model, audio, job["islands"], dist=dist, broadcast_weights=True, on_island=on_island,
+                                    fp16=False, **job["opts"])
+    finally:
+        set_script(None)
+    return result, seen
+
+
+def _check_islands_result(result, job, time_tol=0.0, conf_tol=0.0):
+    import json
+    from golden import make_golden_transcribe as G
+    from test_transcribe_host import compare
+    from whisper_timestamped.sharding import merge_island_results
+    islands = [tuple(x) for x in job["islands"]]
+    got = json.loads(json.dumps(G.public_view(result), default=float))
+    exp = G.public_view(merge_island_results(job["expected"], islands))
+    exp = json.loads(json.dumps(exp, default=float))
+    assert got["speech_activity"] == [{"start": s, "end": e} for s, e in islands]
+    worst = compare(got, exp, time_tol=time_tol, conf_tol=conf_tol, logprob_tol=1e-6 if time_tol == 0 else 2e-4)
+    # the merge itself, on numbers read off the golden: first word of island 1 sits 15.0 s after its crop-relative time
+    n0 = len(job["expected"][0]["segments"])
+    w_crop = job["expected"][1]["segments"][0]["words"][0]
+    w_job = got["segments"][n0]["words"][0]
+    assert w_job["text"] == w_crop["text"] and abs(w_job["start"] - (w_crop["start"] + 15.0)) <= time_tol + 1e-9
+    assert got["segments"][n0]["seek"] == job["expected"][1]["segments"][0]["seek"] + 1500
+    assert [s["id"] for s in got["segments"]] == list(range(len(got["segments"])))
+    starts = [s["start"] for s in got["segments"]]
+    assert starts == sorted(starts)
+    return worst
+
+
+def test_islands_job_single_rank(monkeypatch):
+    job = _islands_job()
+    result, seen = _run_islands_job(None, job, monkeypatch)
+    assert seen == [0, 1, 2, 3]
+    _check_islands_result(result, job)
+
+
+def _islands_worker(rank, world, port, out_path):
+    for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    patch = pytest.MonkeyPatch()
+    try:
+        job = _islands_job()
+        result, seen = _run_islands_job(dist, job, patch)
+        owned = [None] * world
+        dist.all_gather_object(owned, seen)
+        assert sorted(i for part in owned for i in part) == [0, 1, 2, 3] and all(len(part) > 0 for part in owned)
+        if rank == 0:
+            _check_islands_result(result, job)
+            open(out_path, "w").write("ok " + repr(owned))
+        else:
+            assert result is None
+        dist.barrier()
+    finally:
+        patch.undo()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_islands_job_two_ranks(tmp_path):
+    out = tmp_path / "islands.txt"
+    mp.spawn(_islands_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text().startswith("ok ")

@@ -114,3 +114,87 @@ class ResultGatherer:
             step += self.every
         rec = buf[step * self.rec:(step + 1) * self.rec]
         return rec[: self.n_jumps], rec[self.n_jumps:].view(torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Long-form jobs: VAD islands as the sharding unit (BASELINE config 4)
+# ----------------------------------------------------------------------------------------------------------------------
+def _shift(x, t0):
+    return round(x + t0, 2)
+
+
+def merge_island_results(results, islands):
+    """results[i]: the transcribe() dictionary of island i, on the time axis of ITS crop; islands[i] = (start_s, end_s)
+    in the full recording.  Returns one dictionary on the time axis of the recording: texts concatenated, segment ids
+    renumbered, `seek` (10 ms mel frames) / segment / word times shifted by the island start, `speech_activity` = the
+    islands (the key the reference fills when VAD is on, transcribe.py:352-355).  `language` / `language_probs` are
+    those of the first island."""
+    out = {"text": "", "segments": [], "language": None}
+    for (t0, _t1), r in zip(islands, results):
+        if out["language"] is None:
+            out["language"] = r.get("language")
+            if "language_probs" in r:
+                out["language_probs"] = r["language_probs"]
+        out["text"] += r["text"]
+        for seg in r["segments"]:
+            seg = dict(seg)
+            seg["id"] = len(out["segments"])
+            seg["seek"] = seg["seek"] + int(round(t0 * 100))
+            seg["start"], seg["end"] = _shift(seg["start"], t0), _shift(seg["end"], t0)
+            if "words" in seg:
+                seg["words"] = [dict(w, start=_shift(w["start"], t0), end=_shift(w["end"], t0)) for w in seg["words"]]
+            out["segments"].append(seg)
+    out["speech_activity"] = [{"start": s, "end": e} for (s, e) in islands]
+    return out
+
+
+def share_audio(dist, audio, device, src: int = 0):
+    """Rank `src` holds the recording (1-D fp32); the others may pass None and receive it (one broadcast)."""
+    if dist is None or dist.get_world_size() == 1:
+        return audio
+    n = torch.tensor([0 if audio is None else audio.numel()], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    buf = audio.to(device=device, dtype=torch.float32) if dist.get_rank() == src \
+        else torch.empty(int(n.item()), dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=src)
+    return buf
+
+
+def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool = False, on_island=None,
+                       sample_rate: int = 16000, **options):
+    """One long recording, many ranks.  `islands` = [(start_s, end_s)] speech islands (an explicit VAD list: the
+    reference's `vad=[...]` form, transcribe.py:1944-1947); every island is an independent unit -- exactly the
+    reference's transcribe() on that island's crop -- so they are dealt to the ranks largest-first by duration with
+    NO data-path collective; every rank transcribes its islands on its own GPU and rank 0 receives the per-island
+    dictionaries (one object gather per job) and merges them (merge_island_results).  Non-zero ranks return None.
+
+    Not the reference's `vad=` mode (that one glues the islands and decodes them as ONE stream, which cannot be split
+    without changing what the decoder is conditioned on); per island the results are the reference's.
+    `audio`: 1-D float tensor on rank 0 (None elsewhere -> broadcast) or on every rank.  `on_island(i)` is called
+    before island i is transcribed (progress / test scripting).  `options` go to transcribe_timestamped()."""
+    from .transcribe import transcribe_timestamped
+    rank = 0 if dist is None else dist.get_rank()
+    world = 1 if dist is None else dist.get_world_size()
+    islands = [(float(s), float(e)) for s, e in islands]
+    assert all(e > s >= 0 for s, e in islands), "islands must be (start, end) pairs in seconds with end > start"
+    if world > 1:
+        if broadcast_weights:
+            broadcast_module_weights(dist, model, src=0)
+        audio = share_audio(dist, audio, model.device)
+    parts = partition_units([e - s for s, e in islands], world)
+    mine = []
+    for i in parts[rank]:
+        s, e = islands[i]
+        crop = audio[int(round(s * sample_rate)):int(round(e * sample_rate))]
+        if on_island is not None:
+            on_island(i)
+        mine.append((i, transcribe_timestamped(model, crop, **options)))
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank != 0:
+            return None
+        mine = [x for part in gathered for x in part]
+    by_index = dict(mine)
+    assert sorted(by_index) == list(range(len(islands)))
+    return merge_island_results([by_index[i] for i in range(len(islands))], islands)
