@@ -17,10 +17,14 @@
 // Mapping: one workgroup per unit, one LANE PER TOKEN ROW (wave w owns rows
 // 64w..64w+63).  A wave sweeps anti-diagonals: at local step s lane l is at
 // frame j = s - l; g[i-1,*] arrives from lane l-1 through one DPP wave_shr:1
-// (no LDS, no barrier).  Waves are pipelined, not barrier-stepped: the last
-// row of wave w is streamed to LDS (bnd[w][j]) and published every 32 frames
-// through an LDS progress word that wave w+1 polls, so a unit costs about
-// F + 64*W + 32*(W-1) dependent steps instead of a barrier per anti-diagonal.
+// (no LDS, no barrier).  Waves are pipelined, not barrier-stepped: lane 63 of
+// wave w streams its row to LDS (bnd[w][j], one ds_write per step) and
+// publishes it every 32 frames through an LDS progress word that wave w+1
+// polls; wave w+1 reads the 32 values of its next block with broadcast LDS
+// loads and uses each one as the lane-0 operand of the wave_shr.  A unit costs
+// about F + 64*W + 32*(W-1) dependent steps instead of a barrier per
+// anti-diagonal, and a step is issue-bound (one wave = one instruction every
+// ~4 cycles), so the per-step instruction count is what the design minimises.
 // Direction bits (2 per cell) live in LDS only (<= 117 KB); each lane streams
 // its own cost row with a 32-frame register prefetch.  Algorithmic HBM bytes:
 // T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its F+T-cell
@@ -31,8 +35,6 @@
 
 namespace wt {
 
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-
 constexpr int BLK = 32;  // steps per block = bits per direction word
 
 #ifdef WT_PROBE  // tools/probes/dtw_probe.hip only: per-wave timestamps (s_memtime) of unit 0
@@ -42,17 +44,21 @@ __device__ long long wt_probe_clk[16];
 #define WT_STAMP(slot) do { } while (0)
 #endif
 
-// 32 consecutive cost values of this lane's row, starting at frame j0 (flat index `flat` = row*F + j0).
-// ALWAYS exactly 8 dwordx4 loads, no branch: hipcc can then keep the prefetch in flight with a counted
-// s_waitcnt (with a divergent slow path it fell back to vmcnt(0) at the first use of the previous block,
-// i.e. the whole memory latency was exposed once per block: measured 3x on the kernel).  Frames outside
-// [0,F) read neighbouring (finite) entries of the same unit -- those cells never feed a valid cell -- and
-// the flat index is clamped into the unit; the last row may read up to 12 bytes past T*F (the read slack include/wtalign.h asks for).
-__device__ __forceinline__ void load_blk(const float *__restrict__ unit, int flat, int last, float (&dst)[BLK]) {
+// 32 consecutive cost values of this lane's row, starting at frame j0 (byte offset `boff` = 4 * (row*F + j0) into
+// the unit).  ALWAYS exactly 8 dwordx4 loads, no branch: hipcc can then keep the prefetch in flight with a counted
+// s_waitcnt (with a divergent slow path it fell back to vmcnt(0) at the first use of the previous block, i.e. the
+// whole memory latency was exposed once per block: measured 3x on the kernel).  The loads are BUFFER loads on a
+// descriptor of the unit (base = its first cost, range = its T*F floats + the 16 bytes of slack include/wtalign.h
+// asks for): frames left of the row start read the previous row's tail (finite; those cells never feed a valid
+// cell), offsets outside the unit -- negative ones wrap to huge unsigned values -- return 0 from the hardware range
+// check.  One VALU instruction per block for the address instead of a clamp + 64-bit address per load.
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_blk(__amdgpu_buffer_rsrc_t unit, int boff, float (&dst)[BLK]) {
 #pragma unroll
     for (int k = 0; k < BLK / 4; ++k) {
-        const int idx = min(max(flat + 4 * k, 0), last);
-        const float4u r = *reinterpret_cast<const float4u *>(unit + idx);
+        const uint4v u = __builtin_amdgcn_raw_buffer_load_b128(unit, boff + 16 * k, 0, 0);
+        const float4v r = __builtin_bit_cast(float4v, u);  // (whole vector: a bit_cast of ONE element reads element 0)
         dst[4 * k] = r.x; dst[4 * k + 1] = r.y; dst[4 * k + 2] = r.z; dst[4 * k + 3] = r.w;
     }
 }
@@ -67,7 +73,8 @@ __device__ __forceinline__ void load_blk_tiny(const float *__restrict__ unit, in
 }
 
 __host__ __device__ inline int dtw_pitch(int F) { return ((F + 63 + BLK - 1) / BLK) | 1; }  // words per row per plane
-__host__ __device__ inline int dtw_bnd_pitch(int F) { return F + 64 + BLK; }                // doubles per boundary row
+__host__ __device__ inline int dtw_bnd_pitch(int F) { return (F + 64 + BLK + 1) & ~1; }      // doubles per boundary row (even: 16-byte rows)
+constexpr int DUMP = 64 + BLK;  // doubles per producer wave: where lanes 0..62 park the per-step store only lane 63 needs
 
 // in-place wave_shr:1 -- lane 0 keeps what `up` already holds (its +inf)
 __device__ __forceinline__ void shift_in(double &up, double g) {
@@ -79,64 +86,42 @@ __device__ __forceinline__ void shift_in(double &up, double g) {
     up = o.d;
 }
 
-// Boundary feed of a consumer wave: lane k of `bv` holds g[64w-1, s0+k] (published by the wave above).  Each step
-// the register is rotated down by one lane (DPP wave_shl:1), so lane 0 always holds the value of the current
-// step and the wave_shr:1 that delivers g[i-1,*] takes it as its "old" operand -- no v_readlane -> SGPR -> VGPR
-// round trip (measured +50 cycles per step), and the rotation sits off the dependent chain.
-__device__ __forceinline__ void rotate_down(double &bv) {
-    union { double d; int i[2]; } b;
-    b.d = bv;
-    b.i[0] = __builtin_amdgcn_update_dpp(b.i[0], b.i[0], 0x130, 0xf, 0xf, false);  // wave_shl:1, lane 63 keeps its own
-    b.i[1] = __builtin_amdgcn_update_dpp(b.i[1], b.i[1], 0x130, 0xf, 0xf, false);
-    bv = b.d;
+// wa = 2wa + (a1 < a2), wb = 2wb + (b1 < b2): a compare into VCC and an add-with-carry per plane (hipcc emits
+// cndmask + shift + or instead).  ONE asm statement for both planes: between two separate statements hipcc's hazard
+// recogniser, blind to their contents, puts an s_nop that costs the wave a whole issue slot every step.
+__device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1, double a2, double b1, double b2) {
+    asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                 "v_cmp_lt_f64 vcc, %4, %5\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+                 : "+v"(wa), "+v"(wb) : "v"(a1), "v"(a2), "v"(b1), "v"(b2) : "vcc");
 }
-
-// w = 2w + (a < b): one compare into VCC and one add-with-carry (hipcc emits cndmask + shift + or instead)
-__device__ __forceinline__ void plane_bit(uint32_t &w, double a, double b) {
-    asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(a), "v"(b) : "vcc");
-}
-// Cross-lane shift register for the boundary row: lane 0 <- best[lane 63], lane l <- acc[lane l-1].
-// After 32 pushes lane l (< 32) holds the value of step 31-l.  All lanes execute it: no exec juggling, no LDS
-// (a per-step ds_write from lane 63 measured +35 cycles/step as an all-lane same-address store and far more
-// when predicated; these four DPP moves cost ~16).
-__device__ __forceinline__ void push_lane63(double &acc, double best) {
-    union { double d; int i[2]; } b, t, a;
-    b.d = best;
-    a.d = acc;
-    t.i[0] = __builtin_amdgcn_mov_dpp(b.i[0], 0x13C, 0xf, 0xf, false);  // wave_ror:1 -> lane 0 = best[63]
-    t.i[1] = __builtin_amdgcn_mov_dpp(b.i[1], 0x13C, 0xf, 0xf, false);
-    t.i[0] = __builtin_amdgcn_update_dpp(t.i[0], a.i[0], 0x138, 0xf, 0xf, false);  // wave_shr:1, lane 0 keeps t
-    t.i[1] = __builtin_amdgcn_update_dpp(t.i[1], a.i[1], 0x138, 0xf, 0xf, false);
-    acc = t.d;
-}
-
-// One 32-step block of the anti-diagonal sweep.  EDGE: this wave has a
-// producer wave above it (lane 0 takes g[i-1,*] from lane k of `bv`).
+// One 32-step block of the anti-diagonal sweep.
+// EDGE: this wave has a producer wave above it; edge[k] = g[64w-1, s0+k] (the same value in every lane, read from
+// the boundary row with broadcast LDS loads before the block) becomes the "old" operand of the wave_shr:1 that
+// delivers g[i-1,*], i.e. what lane 0 receives -- no rotation, no copy: 2 DPP moves per step like the first wave.
+// PUBLISH: a consumer wave below; every lane stores its `best` of step k at pub[k] -- lane 63's pointer walks the
+// boundary row, the other lanes' pointers sit in a 64+32-double parking area (distinct addresses: no bank
+// conflict, no exec juggling) -- one ds_write per step instead of a 4-DPP cross-lane shift register.
 // u0/u1 alternate as "g[i-1,j]" and "g[i-1,j-1]" so that no register is copied.
 template <bool EDGE, bool PUBLISH, bool DIST>
-__device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1, double bv,
-                                            uint32_t &wa, uint32_t &wb, double &pubacc, int s0, int sfinal,
-                                            double &gfinal) {
+__device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1,
+                                            const double (&edge)[BLK], uint32_t &wa, uint32_t &wb, double *pub, int s0,
+                                            int sfinal, double &gfinal) {
 #pragma unroll
     for (int k = 0; k < BLK; ++k) {
         double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
         const double diag = (k & 1) ? u0 : u1;   // g[i-1, j-1] (written one step ago)
-        if (EDGE) {
-            up = wave_shr1(g, bv);  // lane 0 <- edge value of this step (lane 0 of bv), lane l <- g of lane l-1
-            rotate_down(bv);
-        } else {
-            shift_in(up, g);        // lane 0 keeps its +inf
-        }
+        if (EDGE) up = wave_shr1(g, edge[k]);    // lane 0 <- edge value of this step, lane l <- g of lane l-1
+        else shift_in(up, g);                    // lane 0 keeps its +inf
         const double c = (double)cur[k];
         const double p1 = diag + c;
         const double p2 = g + c;
         const double p3 = up + c;
         const double m12 = __builtin_fmin(p1, p2);
         const double best = __builtin_fmin(m12, p3);
-        plane_bit(wa, p2, p1);   // plane A: "same token, previous frame" beats the diagonal
-        plane_bit(wb, p3, m12);  // plane B: "previous token, same frame" beats both
+        // plane A: "same token, previous frame" beats the diagonal; plane B: "previous token, same frame" beats both
+        plane_bits(wa, wb, p2, p1, p3, m12);
         g = best;
-        if (PUBLISH) push_lane63(pubacc, best);
+        if (PUBLISH) pub[k] = best;
         if (DIST && s0 + k == sfinal) gfinal = best;
     }
 }
@@ -161,16 +146,16 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
 
     uint2 *plane = reinterpret_cast<uint2 *>(smem);          // [nw*64][pitch] (.x = plane A word, .y = plane B word)
     double *bnd = reinterpret_cast<double *>(plane + (size_t)nw * 64 * pitch);  // [nw-1][bpitch], bnd[w][64 + j]
-    double *dump = bnd + (size_t)(nw - 1) * bpitch;         // [BLK]
-    int *prog = reinterpret_cast<int *>(dump + BLK);         // [nw-1]
+    double *park = bnd + (size_t)(nw - 1) * bpitch;          // [nw-1][DUMP]
+    int *prog = reinterpret_cast<int *>(park + (size_t)(nw - 1) * DUMP);  // [nw-1]
     if (threadIdx.x < nw) prog[threadIdx.x] = 0;
     __syncthreads();
     WT_STAMP(wave);
 
     const float *unit = cost + d.cost_offset;
     if ((F < 4 || T * F < 36) != TINY) return;      // block-uniform: tiny units go to the element-wise instantiation
-    const int last = T * F - 1;
-    const int flat0 = (row_ok ? i : T) * F - lane;  // flat index of frame j = -lane of this lane's row
+    const __amdgpu_buffer_rsrc_t ubuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(unit), 0, T * F * 4 + 16, 0x00020000);
+    const int boff0 = 4 * ((row_ok ? i : T) * F - lane);  // byte offset of frame j = -lane of this lane's row
     const double INF = __builtin_inf();
     double g = INF;                      // g[i, j-1]
     double u0 = INF;                     // g[i-1, j] / g[i-1, j-1], alternating
@@ -179,29 +164,40 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     const int sfinal = F - 1 + lane;
     uint32_t wa = 0, wb = 0;
     float bufA[BLK], bufB[BLK];
-    if (TINY) load_blk_tiny(unit, i, -lane, T, F, bufA); else load_blk(unit, flat0, last, bufA);
-    // where this lane publishes its g: lane 63 of a producer wave -> bnd[wave][64 + j], j = s - 63
+    if (TINY) load_blk_tiny(unit, i, -lane, T, F, bufA); else load_blk(ubuf, boff0, bufA);
+    // where a producer wave stores its per-step `best`: lane 63 (row 64w+63, frame j = s - 63) -> bnd[w][64 + j] =
+    // bnd[w][1 + s]; the other lanes -> their own slot of the parking area
     const bool producer = wave < nw - 1;
-    double *pubrow = bnd + (size_t)(producer ? wave : 0) * bpitch + 1;  // step s of lane 63 -> pubrow[s] = bnd[w][64 + j]
-    double pubacc = 0.0;
+    const int pw = producer ? wave : 0;
+    double *pub = (lane == 63) ? bnd + (size_t)pw * bpitch + 1 : park + (size_t)pw * DUMP + lane;
+    const int pubinc = (lane == 63) ? BLK : 0;
+    const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
 
     auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
         if (TINY) load_blk_tiny(unit, i, s0 + BLK - lane, T, F, nxt);
-        else load_blk(unit, flat0 + s0 + BLK, last, nxt);  // prefetch the next block (~2k cycles ahead)
+        else load_blk(ubuf, boff0 + 4 * (s0 + BLK), nxt);  // prefetch the next block (~2k cycles ahead)
+        double edge[BLK];
         if (wave > 0) {
             const int need = min(s0 + BLK, F);
             while (__hip_atomic_load(&prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
                 __builtin_amdgcn_s_sleep(1);
-            double bv = INF;
-            if (lane < BLK && s0 + lane < F) bv = bnd[(size_t)(wave - 1) * bpitch + 64 + s0 + lane];
-            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, bv, wa, wb, pubacc, s0, sfinal, gfinal);
-            else sweep_block<true, false, DIST>(cur, g, u0, u1, bv, wa, wb, pubacc, s0, sfinal, gfinal);
+            // frames >= F of the boundary row are never written: whatever is read there only feeds cells with
+            // j >= F, which feed nothing valid; the block base is clamped so that the reads stay inside the row
+            const double2 *e2 = reinterpret_cast<const double2 *>(erow + min(64 + s0, bpitch - BLK));
+#pragma unroll
+            for (int k = 0; k < BLK / 2; ++k) {
+                const double2 v = e2[k];
+                edge[2 * k] = v.x;
+                edge[2 * k + 1] = v.y;
+            }
+            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
+            else sweep_block<true, false, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
         } else {
-            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, INF, wa, wb, pubacc, s0, sfinal, gfinal);
-            else sweep_block<false, false, DIST>(cur, g, u0, u1, INF, wa, wb, pubacc, s0, sfinal, gfinal);
+            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
+            else sweep_block<false, false, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
         }
         plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
-        if (producer && lane < BLK) pubrow[s0 + BLK - 1 - lane] = pubacc;  // lane l holds step s0 + 31 - l
+        pub += pubinc;
         if (producer && lane == 0) {
             const int done = min(max(s0 + BLK - 63, 0), F);  // frames of row 64w+63 finished so far
             __hip_atomic_store(&prog[wave], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -218,43 +214,69 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     WT_STAMP(8);
 
     // ---- backtrack (dtw/_backtrack.py) + jumps (transcribe.py:1648-1652) ----
-    // step s of row r sits at bit (31 - (s & 31)) of word s >> 5:  A=1,B=0 -> dir 2; B=1 -> dir 3; else dir 1
+    // step s of row r sits at bit (31 - (s & 31)) of word s >> 5:  A=1,B=0 -> dir 2; B=1 -> dir 3; else dir 1.
+    // The walk is a chain of dependent steps on ONE wave, so what it must avoid is an LDS round trip (and taken
+    // branches) per row.  Lane l loads the two plane words around the current step index for row bi - l (a 64-step
+    // window: consecutive rows of a 64-row group move left by a few steps each, so one window serves several rows);
+    // the walk itself runs on the scalar unit: v_readlane of that row's words, one 64-bit "first cell at or below
+    // this step that is not direction 2" (s_ff1_i32_b64), and the row's jump goes into lane (row & 63) of one
+    // VGPR; each 64-row group leaves with one coalesced store.  A new window is loaded only when the walk leaves it.
     int32_t *jp = jumps + d.jumps_offset;
-    int bi = T - 1, bj = F - 1;
-    int len = 1;
-    if (lane == 0) jp[T] = F - 1;
+    int bi = T - 1;
+    int r = bi & 63;
+    int s = F - 1 + r;   // step index of the current cell = frame + (row & 63)
+    int ups = 0;         // direction-3 moves: path length = F + ups
+    int jv = 0;
+    int win = 0, top = 0;
+    uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+    bool reload = true;
     while (bi > 0) {
-        const int s = bj + (bi & 63);
-        const int p = s & 31;
-        const uint2 AB = plane[(size_t)bi * pitch + (s >> 5)];
-        // wave-uniform walk: move it to the scalar unit (SALU ops issue in 1 cycle, no VALU dependent-issue latency)
-        const uint32_t A = __builtin_amdgcn_readfirstlane(AB.x), B = __builtin_amdgcn_readfirstlane(AB.y);
-        // run of dir-2 steps going down from step position p: bits (31-p) upward
-        uint32_t notrun = ~(A & ~B);                    // 1 where dir != 2
-        notrun &= 0xFFFFFFFFu << (31 - p);              // only positions <= p
-        if (notrun == 0) {
-            bj -= p + 1;
-            len += p + 1;
+        if (reload) {
+            win = max((s >> 5) - 1, 0);
+            top = bi;
+            const uint2 *rowp = plane + (size_t)max(bi - lane, 0) * pitch + win;
+            const uint2 w0 = rowp[0], w1 = rowp[1];
+            a0 = w0.x; b0 = w0.y; a1 = w1.x; b1 = w1.y;
+            reload = false;
+        }
+        const int sel = top - bi;
+        const uint64_t A = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)a0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)a1, sel);
+        const uint64_t B = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)b1, sel);
+        const int t = s - 32 * win;                                  // position inside the window: bit 63 - t
+        const uint64_t stop = (~A | B) & (~0ull << (63 - t));       // cells at positions <= t that are NOT direction 2
+        if (__builtin_expect(stop == 0, 0)) {   // direction 2 down to the window's edge: continue in the words below
+            s = 32 * win - 1;
+            reload = true;
             continue;
         }
-        const int bit = __builtin_ctz(notrun);          // lowest set bit = highest step position <= p
-        const int q = 31 - bit;
-        bj -= p - q;
-        len += p - q;
-        if (lane == 0) jp[bi] = bj;
-        if (!((B >> bit) & 1u)) --bj;                   // dir 1: diagonal; dir 3: previous token, same frame
+        const int bit = __builtin_ctzll(stop);
+        s = 32 * win + 63 - bit;                               // the cell where the path leaves the row
+        jv = (lane == r) ? s - r : jv;                        // jumps[bi] = its frame
+        const int up = (int)(B >> bit) & 1;                   // dir 3: previous token, same frame; dir 1: diagonal
+        ups += up;
+        s += up - 2;                                          // frame -= !up, row & 63 -= 1
+        reload = s < 32 * win;
+        if (__builtin_expect(r == 0, 0)) {                    // leaving a 64-row group
+            if (bi + lane < T) jp[bi + lane] = jv;
+            r = 64;
+            s += 64;
+            reload = true;
+        }
+        --r;
         --bi;
-        ++len;
     }
-    len += bj;  // row 0: straight left to (0,0)
+    const int len = F + ups;
+    if (lane > 0 && lane < T) jp[lane] = jv;
     if (lane == 0) {
         jp[0] = 0;
+        jp[T] = F - 1;
         if (path_len) path_len[blockIdx.x] = len;
     }
     WT_STAMP(9);
     if (path_i && path_j) {
         int32_t *pi = path_i + d.path_offset, *pj = path_j + d.path_offset;
-        bi = T - 1; bj = F - 1;
+        int bj = F - 1;
+        bi = T - 1;
         int pos = len - 1;
         while (true) {
             if (lane == 0) { pi[pos] = bi; pj[pos] = bj; }
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
 }
 
 size_t dtw_lds_bytes(int nw, int F) {
-    return (size_t)2 * nw * 64 * dtw_pitch(F) * 4 + ((size_t)(nw - 1) * dtw_bnd_pitch(F) + BLK) * 8 + 16;
+    return (size_t)2 * nw * 64 * dtw_pitch(F) * 4 + (size_t)(nw - 1) * (dtw_bnd_pitch(F) + DUMP) * 8 + 16;
 }
 
 template <bool DIST, bool TINY>
