@@ -30,6 +30,7 @@
 // T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its F+T-cell
 // dependency chain; throughput comes from the batch.
 #include <mutex>
+#include <type_traits>
 
 #include "wt_common.h"
 
@@ -127,7 +128,7 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
 }
 
 template <bool DIST, bool TINY>
-__global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
+__global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
                            int32_t *__restrict__ path_i, int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
                            double *__restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     if ((T + 63) / 64 != nw) return;  // block-uniform: unit belongs to another launch class
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lives in an SGPR
     const int i = wave * 64 + lane;  // token row
     const bool row_ok = i < T;
     const int nsteps = F + 63;
@@ -173,39 +174,54 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     const int pubinc = (lane == 63) ? BLK : 0;
     const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
 
-    auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
-        if (TINY) load_blk_tiny(unit, i, s0 + BLK - lane, T, F, nxt);
-        else load_blk(ubuf, boff0 + 4 * (s0 + BLK), nxt);  // prefetch the next block (~2k cycles ahead)
-        double edge[BLK];
-        if (wave > 0) {
-            const int need = min(s0 + BLK, F);
-            while (__hip_atomic_load(&prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                __builtin_amdgcn_s_sleep(1);
-            // frames >= F of the boundary row are never written: whatever is read there only feeds cells with
-            // j >= F, which feed nothing valid; the block base is clamped so that the reads stay inside the row
-            const double2 *e2 = reinterpret_cast<const double2 *>(erow + min(64 + s0, bpitch - BLK));
+    // The role of a wave (has a producer above / a consumer below) is decided ONCE, outside the sweep: each role runs
+    // its own loop, so a block costs one taken branch instead of a chain of exec-masked skips over the other roles'
+    // code (a taken branch is ~20 cycles for a lone wave, a skipped one ~11; measured ~15 cycles per step overall).
+    auto sweep = [&](auto edge_c, auto publish_c) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_c)::value, PUBLISH = decltype(publish_c)::value;
+        auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
+            if (TINY) load_blk_tiny(unit, i, s0 + BLK - lane, T, F, nxt);
+            else load_blk(ubuf, boff0 + 4 * (s0 + BLK), nxt);  // prefetch the next block (~2k cycles ahead)
+            // the loads stay HERE, a whole block ahead of their first use (without this fence hipcc rotates the loop
+            // and sinks them to just before the use: the memory latency is then exposed once per iteration; `cost`
+            // is deliberately not __restrict__: loads the compiler knows to be invariant ignore the fence)
+            asm volatile("" ::: "memory");
+            double edge[BLK];
+            if (EDGE) {
+                const int need = min(s0 + BLK, F);
+                while (__hip_atomic_load(&prog[wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                    __builtin_amdgcn_s_sleep(1);
+                // frames >= F of the boundary row are never written: whatever is read there only feeds cells with
+                // j >= F, which feed nothing valid; the block base is clamped so that the reads stay inside the row
+                const double2 *e2 = reinterpret_cast<const double2 *>(erow + min(64 + s0, bpitch - BLK));
 #pragma unroll
-            for (int k = 0; k < BLK / 2; ++k) {
-                const double2 v = e2[k];
-                edge[2 * k] = v.x;
-                edge[2 * k + 1] = v.y;
+                for (int k = 0; k < BLK / 2; ++k) {
+                    const double2 v = e2[k];
+                    edge[2 * k] = v.x;
+                    edge[2 * k + 1] = v.y;
+                }
             }
-            if (producer) sweep_block<true, true, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-            else sweep_block<true, false, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-        } else {
-            if (producer) sweep_block<false, true, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-            else sweep_block<false, false, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-        }
-        plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
-        pub += pubinc;
-        if (producer && lane == 0) {
-            const int done = min(max(s0 + BLK - 63, 0), F);  // frames of row 64w+63 finished so far
-            __hip_atomic_store(&prog[wave], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            sweep_block<EDGE, PUBLISH, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
+            plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
+            if (PUBLISH) {
+                pub += pubinc;
+                if (lane == 0) {
+                    const int done = min(max(s0 + BLK - 63, 0), F);  // frames of row 64w+63 finished so far
+                    __hip_atomic_store(&prog[wave], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += 2 * BLK) {
+            block(bufA, bufB, s0);
+            if (s0 + BLK < nsteps) block(bufB, bufA, s0 + BLK);
         }
     };
-    for (int s0 = 0; s0 < nsteps; s0 += 2 * BLK) {
-        block(bufA, bufB, s0);
-        if (s0 + BLK < nsteps) block(bufB, bufA, s0 + BLK);
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    if (wave == 0) {
+        if (producer) sweep(no{}, yes{}); else sweep(no{}, no{});
+    } else {
+        if (producer) sweep(yes{}, yes{}); else sweep(yes{}, no{});
     }
     if (DIST && i == T - 1) dist[blockIdx.x] = gfinal;
     WT_STAMP(4 + wave);
@@ -227,43 +243,40 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *__restrict__ cost
     int s = F - 1 + r;   // step index of the current cell = frame + (row & 63)
     int ups = 0;         // direction-3 moves: path length = F + ups
     int jv = 0;
-    int win = 0, top = 0;
-    uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
-    bool reload = true;
     while (bi > 0) {
-        if (reload) {
-            win = max((s >> 5) - 1, 0);
-            top = bi;
-            const uint2 *rowp = plane + (size_t)max(bi - lane, 0) * pitch + win;
-            const uint2 w0 = rowp[0], w1 = rowp[1];
-            a0 = w0.x; b0 = w0.y; a1 = w1.x; b1 = w1.y;
-            reload = false;
-        }
-        const int sel = top - bi;
-        const uint64_t A = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)a0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)a1, sel);
-        const uint64_t B = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)b1, sel);
-        const int t = s - 32 * win;                                  // position inside the window: bit 63 - t
-        const uint64_t stop = (~A | B) & (~0ull << (63 - t));       // cells at positions <= t that are NOT direction 2
-        if (__builtin_expect(stop == 0, 0)) {   // direction 2 down to the window's edge: continue in the words below
-            s = 32 * win - 1;
-            reload = true;
-            continue;
-        }
-        const int bit = __builtin_ctzll(stop);
-        s = 32 * win + 63 - bit;                               // the cell where the path leaves the row
-        jv = (lane == r) ? s - r : jv;                        // jumps[bi] = its frame
-        const int up = (int)(B >> bit) & 1;                   // dir 3: previous token, same frame; dir 1: diagonal
-        ups += up;
-        s += up - 2;                                          // frame -= !up, row & 63 -= 1
-        reload = s < 32 * win;
-        if (__builtin_expect(r == 0, 0)) {                    // leaving a 64-row group
-            if (bi + lane < T) jp[bi + lane] = jv;
-            r = 64;
+        // window: words win, win + 1 of rows bi, bi - 1, ... (lane l: row bi - l)
+        const int win = max((s >> 5) - 1, 0);
+        const int base = 32 * win;
+        const int top = bi;
+        const uint2 *rowp = plane + (size_t)max(bi - lane, 0) * pitch + win;
+        const uint2 w0 = rowp[0], w1 = rowp[1];
+        const int a0 = (int)w0.x, b0 = (int)w0.y, a1 = (int)w1.x, b1 = (int)w1.y;
+        bool more;
+        do {   // one row per iteration, no memory access, one taken branch
+            const int sel = top - bi;
+            const uint64_t A = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(a0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane(a1, sel);
+            const uint64_t B = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(b0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane(b1, sel);
+            // cells at window positions <= s - base (bit 63 - position) that are NOT direction 2
+            const uint64_t stop = (~A | B) & (~0ull << (base + 63 - s));
+            if (__builtin_expect(stop == 0, 0)) {   // direction 2 down to the window's edge: go on in the words below
+                s = base - 1;
+                break;
+            }
+            const int bit = __builtin_ctzll(stop);
+            s = base + 63 - bit;                              // the cell where the path leaves the row
+            jv = (lane == r) ? s - r : jv;                    // jumps[bi] = its frame
+            const int up = (int)(B >> bit) & 1;               // dir 3: previous token, same frame; dir 1: diagonal
+            ups += up;
+            s += up - 2;                                      // frame -= !up, row & 63 -= 1
+            --r;
+            --bi;
+            more = (s >= base) & (r >= 0) & (bi > 0);
+        } while (more);
+        if (r < 0) {                                          // left a 64-row group: rows bi+1 .. bi+64
+            if (bi + 1 + lane < T) jp[bi + 1 + lane] = jv;
+            r = 63;
             s += 64;
-            reload = true;
         }
-        --r;
-        --bi;
     }
     const int len = F + ups;
     if (lane > 0 && lane < T) jp[lane] = jv;
