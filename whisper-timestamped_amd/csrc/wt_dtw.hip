@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
             s += up - 2;                                      // frame -= !up, row & 63 -= 1
             --r;
             --bi;
-            more = (s >= base) & (r >= 0) & (bi > 0);
+            more = ((s - base) | r | (bi - 1)) >= 0;      // still inside the window, the row group and the matrix
         } while (more);
         if (r < 0) {                                          // left a 64-row group: rows bi+1 .. bi+64
             if (bi + 1 + lane < T) jp[bi + 1 + lane] = jv;
