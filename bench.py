@@ -208,6 +208,25 @@ def _stage_calls(w):
 LANES = [["logmel", "padding"], ["cost", "dtw"], ["logprob"]]
 
 
+def cu_masked_streams(dev, n_dtw_cus):
+    """Two HIP streams with complementary CU masks (hipExtStreamCreateWithCUMask).  Mask bit i is CU i in the
+    driver's enumeration, which interleaves the XCDs (bit i -> XCD i % 8): the first n bits are n/8 CUs on every XCD."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = (n_cus + 31) // 32
+
+    def make(bits):
+        mask = (ctypes.c_uint32 * words)()
+        for b in bits:
+            mask[b // 32] |= 1 << (b % 32)
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+        assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+        return torch.cuda.ExternalStream(st.value, device=dev)
+    return make(range(n_dtw_cus)), make(range(n_dtw_cus, n_cus))
+
+
 def run_step(w, ev=None, streams=None):
     """One pass of the hot path.  ev: optional {stage: (start_event, end_event)}, recorded on the stream the stage's
     kernels are launched on.  streams: None = everything on the current stream, in order; else 3 torch streams."""
@@ -232,6 +251,25 @@ def run_step(w, ev=None, streams=None):
         if ev: ev["logprob"][0].record(main)
         calls["logprob"](main.cuda_stream)
         if ev: ev["logprob"][1].record(main)
+    elif isinstance(streams, tuple) and streams[0] == "cumask":
+        # log-mel, padding, cost on the whole chip; then the DTW on its own CUs (one workgroup = one CU per unit) beside
+        # the HBM-bound log-prob gather on the other CUs: CU-masked streams, so neither kernel's waves land on the
+        # other's CUs (without masks the gather's waves share the DTW's SIMDs and both kernels slow down)
+        dtw_s, lp_s = streams[1], streams[2]
+        for stage in ("logmel", "padding", "cost"):
+            if ev: ev[stage][0].record(main)
+            calls[stage](main.cuda_stream)
+            if ev: ev[stage][1].record(main)
+        dtw_s.wait_stream(main)
+        lp_s.wait_stream(main)
+        if ev: ev["dtw"][0].record(dtw_s)
+        calls["dtw"](dtw_s.cuda_stream)
+        if ev: ev["dtw"][1].record(dtw_s)
+        if ev: ev["logprob"][0].record(lp_s)
+        calls["logprob"](lp_s.cuda_stream)
+        if ev: ev["logprob"][1].record(lp_s)
+        main.wait_stream(dtw_s)
+        main.wait_stream(lp_s)
     elif isinstance(streams, tuple) and streams[0] == "dtw":
         side = streams[1]
         for stage in ("logmel", "padding", "cost"):
@@ -323,7 +361,8 @@ def main():
                          "pass BEFORE the timed region (events cannot be read back from inside a graph)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: result records of this many steps travel to rank 0 in one RCCL gather")
-    ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel"],
+    ap.add_argument("--dtw-cus", type=int, default=32, help="--overlap cumask: CUs reserved for the DTW stream")
+    ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel", "cumask"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
     args = ap.parse_args()
@@ -362,6 +401,8 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in LANES]
     elif args.overlap in ("dtw", "dtw_logmel"):
         streams = args.overlap, torch.cuda.Stream(device=dev)
+    elif args.overlap == "cumask":
+        streams = ("cumask",) + cu_masked_streams(dev, args.dtw_cus)
 
     def full_step(ev=None):
         run_step(w, ev, streams)
@@ -451,7 +492,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
-                       "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2}[args.overlap],
+                       "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph),
                        "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
