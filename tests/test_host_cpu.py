@@ -216,3 +216,20 @@ def test_transcribe_signature_is_the_reference_one():
     got = [(n, p.default) for n, p in inspect.signature(wt.load_model).parameters.items()]
     assert got == [("name", inspect._empty), ("device", None), ("backend", "openai-whisper"), ("download_root", None),
                    ("in_memory", False)]
+
+
+def test_output_surface_matches_reference():
+    """filtered_keys / flatten / remove_keys / write_csv against what the reference's own functions make of the
+    reference's own results (tests/golden/output_surface.json, written by tests/golden/make_golden_output.py)."""
+    import json
+    from golden.make_golden_output import surface
+    from whisper_timestamped import output
+    here = os.path.dirname(os.path.abspath(__file__))
+    golden = json.load(open(os.path.join(here, "golden", "output_surface.json"), encoding="utf-8"))
+    cases = {c["name"]: c for c in json.load(open(os.path.join(here, "golden", "transcribe_cases.json"), encoding="utf-8"))}
+    assert len(golden) == 5
+    for name, exp in golden.items():
+        got = json.loads(json.dumps(surface(output, cases[name]["expected"])))
+        assert got == exp, name
+    assert list(output.flatten([[1, 2], [3]])) == [1, 2, 3]
+    assert list(output.flatten([{"a": [1]}, {}], "a")) == [1]

@@ -16,6 +16,7 @@ from . import backend as _backend
 from .efficient import transcribe_efficient
 from .naive import transcribe_naive
 from .naive import get_audio_tensor
+from .output import filtered_keys, flatten, remove_keys, write_csv  # noqa: F401  (reference: same module, same names)
 from .postprocess import ensure_increasing_positions, remove_last_null_duration_words
 from .vad import check_vad_method, remove_non_speech
 from .words import AUDIO_TIME_PER_TOKEN, HOP_LENGTH, N_FRAMES, SAMPLE_RATE
