@@ -127,6 +127,15 @@ int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, c
                    const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
 
+/* T.py:1656-1672 (detect_disfluencies): for every token row t of every unit, scipy.signal.find_peaks(-cost[t,
+ * jumps[t]:jumps[t+1]], width=min_width, prominence=min_prominence) in f64 as scipy does; when more than one peak
+ * survives, the token's start moves to round(left_ips[-1]) + jumps[t].
+ *   cost, jumps : what wt_cost_batch / wt_dtw_batch wrote (same descriptors)
+ *   jumps_start : device int32, T+1 per unit at jumps_offset: [t] = the (possibly moved) start of token t,
+ *                 [T] = jumps[T].  The reference passes width=3, prominence=0.02. */
+int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps,
+                        int32_t *jumps_start, double min_prominence, double min_width, void *stream);
+
 /* T.py:1795-1805 find_start_padding on a batch of (n_mels, n_cols) log-mel
  * windows: out[b] = None(-1) if the last column is not all-zero, else the
  * index after the last column in [1, n_cols-2] that differs from zero, else 0. */

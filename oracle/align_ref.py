@@ -294,6 +294,75 @@ def split_tokens_on_spaces_ref(tokens, tokenizer, remove_punctuation_from_words=
 # --------------------------------------------------------------------------
 # Full alignment of one segment (transcribe.py:1428-1793, plotting omitted)
 # --------------------------------------------------------------------------
+def jumps_start_ref(cost, jumps, min_prominence=0.02, min_width=3):
+    """transcribe.py:1656-1672 without the tokenizer part: the (possibly moved) start frame of every token row.
+    cost: (T,F) local-cost matrix (f64 or f32; scipy works in f64 either way), jumps: T+1 frames.  Uses
+    scipy.signal.find_peaks itself, like the reference."""
+    jumps = np.asarray(jumps)
+    out = jumps.copy()
+    for t, (begin, end) in enumerate(zip(jumps[:-1], jumps[1:])):
+        peaks, props = find_peaks(-np.asarray(cost[t, begin:end], dtype=np.float64), width=min_width, prominence=min_prominence)
+        if len(peaks) > 1:
+            out[t] = round(props["left_ips"][-1]) + begin
+    return out
+
+
+def jumps_start_restated(cost, jumps, min_prominence=0.02, min_width=3.0):
+    """The same answer WITHOUT scipy: its algorithm (_local_maxima_1d, _peak_prominences, _peak_widths of
+    scipy/signal/_peak_finding_utils.pyx) spelled out loop by loop -- the text the HIP kernel wt_peaks.hip follows.
+    tests/test_oracle.py holds it against jumps_start_ref on random profiles."""
+    jumps = np.asarray(jumps)
+    out = jumps.copy()
+    for t, (begin, end) in enumerate(zip(jumps[:-1], jumps[1:])):
+        x = -np.asarray(cost[t, begin:end], dtype=np.float64)
+        n = len(x)
+        kept, last_left = 0, 0.0
+        i, i_last = 1, n - 1
+        while i < i_last:
+            if x[i - 1] < x[i]:
+                ahead = i + 1
+                while ahead < i_last and x[ahead] == x[i]:
+                    ahead += 1
+                if x[ahead] < x[i]:
+                    peak = (i + ahead - 1) // 2
+                    i = ahead
+                    xp = x[peak]
+                    left_min = right_min = xp
+                    lb = rb = peak
+                    k = peak
+                    while k >= 0 and x[k] <= xp:
+                        if x[k] < left_min:
+                            left_min, lb = x[k], k
+                        k -= 1
+                    k = peak
+                    while k <= i_last and x[k] <= xp:
+                        if x[k] < right_min:
+                            right_min, rb = x[k], k
+                        k += 1
+                    prominence = xp - max(left_min, right_min)
+                    if min_prominence <= prominence:
+                        height = xp - prominence * 0.5
+                        k = peak
+                        while lb < k and height < x[k]:
+                            k -= 1
+                        left_ip = float(k)
+                        if x[k] < height:
+                            left_ip += (height - x[k]) / (x[k + 1] - x[k])
+                        k = peak
+                        while k < rb and height < x[k]:
+                            k += 1
+                        right_ip = float(k)
+                        if x[k] < height:
+                            right_ip -= (height - x[k]) / (x[k - 1] - x[k])
+                        if min_width <= right_ip - left_ip:
+                            kept += 1
+                            last_left = left_ip
+            i += 1
+        if kept > 1:
+            out[t] = round(last_left) + begin
+    return out
+
+
 def perform_word_alignment_ref(tokens, attention_weights, tokenizer, use_space=True, mfcc=None,
                                refine_whisper_precision_nframes=0, remove_punctuation_from_words=False,
                                include_punctuation_in_timing=False, unfinished_decoding=False,

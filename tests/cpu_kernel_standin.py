@@ -60,6 +60,7 @@ def install(monkeypatch):
             cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
             r = O.dtw_ref(cost)
             jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
-            out.append(alignment.finish_unit(u, jumps, cost.astype(np.float32)))
+            starts = O.jumps_start_ref(cost, jumps) if u.detect_disfluencies else None
+            out.append(alignment.finish_unit(u, jumps, starts))
         return out
     monkeypatch.setattr(alignment.AlignmentBatch, "run", run)

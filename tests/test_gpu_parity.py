@@ -427,3 +427,41 @@ def test_reference_side_stub():
     got_cost = cost.cpu().numpy().reshape(T, end - start)
     np.testing.assert_allclose(got_cost, want_cost, rtol=2e-5, atol=2e-7)
     assert np.abs(jumps.astype(np.int64) - want).max() <= 1
+
+
+def test_disfluency_kernel_vs_scipy():
+    """wt_disfluency_batch (T.py:1656-1672: where the last attention peak of every token span starts) against the
+    oracle, which calls scipy.signal.find_peaks the way the reference does.  Integer output: must be identical.
+    Units of every shape class, profiles with several bumps per span, a third of them quantised (plateaus, ties)."""
+    from test_oracle import _peaky_cost
+    lib = _lib()
+    L = lib.load()
+    rng = np.random.RandomState(17)
+    shapes = [(1, 40), (3, 400), (7, 1500), (12, 1792), (30, 1500), (64, 1500), (130, 1500), (224, 1500), (256, 1792), (2, 3)]
+    descs = lib.make_descs(len(shapes))
+    costs, jumps = [], []
+    for k, (d, (T, F)) in enumerate(zip(descs, shapes)):
+        d["T"], d["F"] = T, F
+        costs.append(_peaky_cost(rng, T, F, quantised=k % 3 == 0, density=max(1, F // 100)))
+        cuts = np.sort(rng.randint(0, F, size=T - 1)) if T > 1 else np.zeros(0, dtype=np.int64)
+        jumps.append(np.concatenate([[0], cuts, [F - 1]]).astype(np.int32))
+    n_cost, n_jumps, _ = lib.layout_outputs(descs)
+    cost = torch.zeros(n_cost, dtype=torch.float32)
+    jp = torch.zeros(n_jumps, dtype=torch.int32)
+    for d, c, j in zip(descs, costs, jumps):
+        cost[int(d["cost_offset"]):int(d["cost_offset"]) + c.size] = torch.from_numpy(c.ravel())
+        jp[int(d["jumps_offset"]):int(d["jumps_offset"]) + j.size] = torch.from_numpy(j)
+    cost, jp = cost.to(DEV), jp.to(DEV)
+    out = torch.full_like(jp, -7)
+    dd = lib.descs_to_device(descs, DEV)
+    lib._check(L.wt_disfluency_batch(cost.data_ptr(), dd.data_ptr(), len(shapes), jp.data_ptr(), out.data_ptr(), 0.02, 3.0,
+                                      lib._stream()), "wt_disfluency_batch")
+    out = out.cpu().numpy()
+    moved = 0
+    for d, c, j in zip(descs, costs, jumps):
+        want = O.jumps_start_ref(c, j.astype(np.int64))
+        got = out[int(d["jumps_offset"]):int(d["jumps_offset"]) + j.size]
+        assert np.array_equal(got, want), (int(d["T"]), int(d["F"]), np.nonzero(got != want)[0][:5])
+        moved += int((want != j).sum())
+    assert moved > 20
+    assert L.wt_disfluency_batch(0, dd.data_ptr(), 1, jp.data_ptr(), out.ctypes.data, 0.02, 3.0, 0) == -1     # WT_E_BADARG

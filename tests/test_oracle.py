@@ -139,3 +139,33 @@ def test_confidence_rounding():
     lp = torch.tensor([-0.1, -0.2, -1.5])
     assert O.confidence_ref(lp) == round(float(np.exp(np.float32(-0.6))), 3)
     assert O.confidence_ref([]) == 0.0
+
+
+def _peaky_cost(rng, T, F, quantised, density=1):
+    """(T,F) cost rows with several bumps per token span: what find_peaks has to sort out."""
+    x = np.zeros((T, F))
+    for t in range(T):
+        for _ in range(rng.randint(1, 10) * density):
+            c, w, h = rng.uniform(0, F), rng.uniform(0.7, 5.0), rng.uniform(0.01, 0.3)
+            x[t] += h * np.exp(-0.5 * ((np.arange(F) - c) / w) ** 2)
+        x[t] += 0.004 * rng.rand(F)
+    if quantised:                       # plateaus and exact ties
+        x = np.round(x * 64) / 64
+    return (-x).astype(np.float32)
+
+
+def test_peak_restatement_vs_scipy():
+    """The loop-by-loop restatement of scipy's find_peaks(width, prominence) (the text wt_peaks.hip follows) against
+    scipy itself, as the reference calls it (transcribe.py:1663-1666)."""
+    rng = np.random.RandomState(3)
+    moved = 0
+    for trial in range(80):
+        T, F = rng.randint(1, 7), rng.randint(3, 200)
+        cost = _peaky_cost(rng, T, F, quantised=trial % 3 == 0)
+        cuts = np.sort(rng.randint(0, F, size=T - 1)) if T > 1 else np.zeros(0, dtype=np.int64)
+        jumps = np.concatenate([[0], cuts, [F - 1]]).astype(np.int64)
+        ref = O.jumps_start_ref(cost, jumps)
+        got = O.jumps_start_restated(cost, jumps)
+        assert np.array_equal(ref, got), (trial, ref, got)
+        moved += int((ref != jumps).sum())
+    assert moved > 20        # the inputs do exercise the "more than one peak" branch

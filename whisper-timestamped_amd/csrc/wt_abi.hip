@@ -82,6 +82,7 @@ int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int3
               double *, hipStream_t);
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, float *, hipStream_t);
 int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
+int disfluency_batch(const float *, const wt_seg_desc *, int, const int32_t *, int32_t *, double, double, hipStream_t);
 int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
 int capture_rows(const void *, int, int, int, int, const int32_t *, const int32_t *, int, void *, int, int64_t, int64_t,
                  hipStream_t);
@@ -142,6 +143,11 @@ int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, c
                             (hipStream_t)stream);
     if (rc) return rc;
     return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, jumps, path_i, path_j, path_len, dist, (hipStream_t)stream);
+}
+
+int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps, int32_t *jumps_start,
+                        double min_prominence, double min_width, void *stream) {
+    return wt::disfluency_batch(cost, segs_dev, n_seg, jumps, jumps_start, min_prominence, min_width, (hipStream_t)stream);
 }
 
 int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, void *stream) {

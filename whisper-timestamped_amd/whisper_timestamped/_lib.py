@@ -27,7 +27,8 @@ SEG_DTYPE = np.dtype([
 assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
-           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows"]
+           "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
+           "wt_disfluency_batch"]
 
 
 class WtError(RuntimeError):
@@ -54,6 +55,7 @@ def load():
     L.wt_dtw_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.wt_align_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
     L.wt_find_start_padding_batch.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.wt_disfluency_batch.argtypes = [vp, vp, i32, vp, vp, ctypes.c_double, ctypes.c_double, vp]
     L.wt_logprob_gather_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, i32, vp, vp]
     L.wt_logmel_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.wt_capture_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, vp]

@@ -214,19 +214,24 @@ class AlignmentBatch:
                               _lib._ptr(self.path_len), _lib._ptr(self.dist), _lib._stream())
         _lib._check(rc, "wt_align_batch")
         self.descs, self.cost, self.jumps = descs, cost, jumps
-        jumps_host = jumps.cpu().numpy()                       # the one device->host sync of the batch
-        need_cost = self.keep_cost or any(u.detect_disfluencies for u in units)
-        cost_host = cost.cpu().numpy() if need_cost else None
+        both = jumps
+        if any(u.detect_disfluencies for u in units):          # token starts moved to their last attention peak
+            both = torch.empty(2 * n_jumps, dtype=torch.int32, device=dev)
+            both[:n_jumps].copy_(jumps)
+            rc = L.wt_disfluency_batch(cost.data_ptr(), descs_dev.data_ptr(), len(units), jumps.data_ptr(),
+                                       both[n_jumps:].data_ptr(), DISFLUENCY_MIN_PROMINENCE, DISFLUENCY_MIN_WIDTH,
+                                       _lib._stream())
+            _lib._check(rc, "wt_disfluency_batch")
+        both_host = both.cpu().numpy()                         # the one device->host sync of the batch (KBs)
+        jumps_host = both_host[:n_jumps]
+        starts_host = both_host[n_jumps:] if both is not jumps else None
         out = [None] * len(units)
         self._slot = [0] * len(units)                # caller's unit index -> descriptor index
         for k, (d, u) in enumerate(zip(descs, units)):
             j0 = int(d["jumps_offset"])
             jm = jumps_host[j0:j0 + u.T + 1].astype(np.int64)
-            cm = None
-            if cost_host is not None:
-                c0 = int(d["cost_offset"])
-                cm = cost_host[c0:c0 + u.T * u.F].reshape(u.T, u.F)
-            out[order[k]] = finish_unit(u, jm, cm)
+            js = starts_host[j0:j0 + u.T + 1].astype(np.int64) if starts_host is not None else None
+            out[order[k]] = finish_unit(u, jm, js)
             self._slot[order[k]] = k
         return out
 
@@ -244,31 +249,32 @@ class AlignmentBatch:
         return self.path_i[p0:p0 + n], self.path_j[p0:p0 + n]
 
 
-def detect_disfluences(unit: AlignmentUnit, jumps, cost):
-    """transcribe.py:1654-1683 on the host (scipy.signal.find_peaks on the cost
-    rows the kernel produced) -- SURVEY 'next' row N1, off by default in the API."""
-    from scipy.signal import find_peaks
-    jumps_start = jumps.copy()
+DISFLUENCY_MIN_PROMINENCE, DISFLUENCY_MIN_WIDTH = 0.02, 3.0      # find_peaks arguments of transcribe.py:1663-1666
+
+
+def detect_disfluences(unit: AlignmentUnit, jumps, jumps_start):
+    """transcribe.py:1656-1683.  The numeric half -- scipy.signal.find_peaks on every token's span of the cost matrix,
+    and where the last peak starts -- ran on the GPU (wt_disfluency_batch -> jumps_start); what is left for the host
+    is the tokenizer's business: a moved start marks the token as a disfluency unless the token is punctuation, in
+    which case the NEXT token inherits the whole span."""
     disfluences = {}
-    for i_token, (tok, begin, end) in enumerate(zip(unit.tokens, jumps[:-1], jumps[1:])):
-        profile = -cost[i_token, begin:end].astype(np.float64)
-        peaks, props = find_peaks(profile, width=3, prominence=0.02)
-        if len(peaks) > 1:
-            left = [round(x) for x in props["left_ips"]] if "left_ips" in props else props["left_bases"]
-            new_begin = left[-1] + begin
-            jumps_start[i_token] = new_begin
-            if new_begin != begin:
-                if unit.tokenizer.decode_with_timestamps([tok]) not in _punctuation:
-                    disfluences[i_token] = (begin, jumps_start[i_token])
-                else:
-                    disfluences[i_token + 1] = (begin, end)
+    for i_token in np.nonzero(jumps_start[:-1] != jumps[:-1])[0]:
+        i_token = int(i_token)
+        begin, end = int(jumps[i_token]), int(jumps[i_token + 1])
+        if unit.tokenizer.decode_with_timestamps([unit.tokens[i_token]]) not in _punctuation:
+            disfluences[i_token] = (begin, int(jumps_start[i_token]))
+        else:
+            disfluences[i_token + 1] = (begin, end)
     return jumps_start, disfluences
 
 
-def finish_unit(unit: AlignmentUnit, jumps, cost=None):
-    jumps_start, disfluences = jumps, None
+def finish_unit(unit: AlignmentUnit, jumps, jumps_start=None):
+    disfluences = None
     if unit.detect_disfluencies:
-        jumps_start, disfluences = detect_disfluences(unit, jumps, cost)
+        assert jumps_start is not None, "detect_disfluencies: the batch must have run wt_disfluency_batch"
+        jumps_start, disfluences = detect_disfluences(unit, jumps, jumps_start)
+    else:
+        jumps_start = jumps
     return words_from_jumps(jumps, jumps_start, unit.words, unit.word_pieces, unit.word_ids, unit.punct_counts,
                             unit.start_token * AUDIO_TIME_PER_TOKEN, unit.refine_nframes, unit.unfinished_decoding,
                             disfluences)
