@@ -10,8 +10,8 @@
 //   * a local maximum is a sample -- or the middle of a plateau -- strictly above both neighbours; the first and
 //     the last sample never are;
 //   * its prominence is its height above the higher of the two lowest points met while walking left / right until a
-//     strictly higher sample (or the end); those lowest points are its bases (leftmost / rightmost on ties? no:
-//     the FIRST strictly lower value met wins, later equal values do not move the base);
+//     strictly higher sample (or the end); those lowest points are its bases (among equal lows the one met first,
+//     i.e. the one nearest to the peak);
 //   * kept if prominence >= 0.02; its width is measured at half prominence, between the two crossings (linear
 //     interpolation between samples) searched from the peak towards its bases; kept if width >= 3.
 // The matrix is the fp32 cost the cost kernel wrote (the reference's f64 matrix holds exactly these values), the
