@@ -230,29 +230,37 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (act) {
         // ---- stage 2: twiddle by W400^(n2*k1), radix-20 over n2 for this lane's k1 = u ----
         const int ks = u <= 10 ? u : 20 - u;
-        const float cj = u <= 10 ? 1.f : -1.f;
-        float br[20], bi[20];
-        int widx = 0;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 cjv = u <= 10 ? (f2){1.f, 1.f} : (f2){1.f, -1.f};   // k1 > 10: the conjugate of row 20 - k1
+        f2 B[20];
+        int woff = 0;                        // byte offset of W400^(n2*u) in the table
+        const int wstep = u * (int)sizeof(float2);
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) {
-            const float2 v = yp[slot][ks][n2];
-            const float2 w = w400[widx];    // W400^(n2*u); e^{-i t} = (cos t, -sin t)
-            widx += u;
-            const float re = v.x, im = cj * v.y;
-            br[n2] = re * w.x + im * w.y;
-            bi[n2] = im * w.x - re * w.y;
+            const float2 vv = yp[slot][ks][n2];
+            const float2 ww = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(w400) + woff);  // (cos, sin)
+            woff += wstep;
+            asm volatile("" : "+v"(woff));   // keep it an add: unrolled, hipcc turns it into n2*u (v_mul_lo_u32: 4x the cost)
+            // (re + i im)(cos - i sin) = cos*(re, im) + sin*(im, -re): one packed multiply + one packed fma whose
+            // operand modifiers do the swap and the sign (hipcc spends a v_xor and a v_mov on them)
+            const f2 v = (f2){vv.x, vv.y} * cjv;
+            const f2 w = (f2){ww.x, ww.y};
+            f2 b = v * (f2){w.x, w.x};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(b) : "v"(v), "v"(w));
+            B[n2] = b;
         }
         // X[k2] = sum_n2 b[n2] e^{-2 pi i n2 k2 / 20}: pair n2 with 20-n2 and k2 with 10-k2, and keep (re, im) as
         // one 64-bit operand so that each multiply-add is a v_pk_fma_f32: 108 packed MACs instead of 800 scalar ones.
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 P[10], Ms[10];                      // P = b[n] + b[20-n];  Ms = (mi, -mr) with (mr, mi) = b[n] - b[20-n]
+        // The sine terms multiply by -i, i.e. swap (re, im) -> (im, -re): that swap is linear, so it is applied once
+        // per output to the accumulated sum instead of once per input.
+        f2 P[10], D[10];                       // P = b[n] + b[20-n],  D = b[n] - b[20-n]
 #pragma unroll
         for (int n = 1; n < 10; ++n) {
-            P[n] = (f2){br[n] + br[20 - n], bi[n] + bi[20 - n]};
-            Ms[n] = (f2){bi[n] - bi[20 - n], br[20 - n] - br[n]};
+            P[n] = B[n] + B[20 - n];
+            D[n] = B[n] - B[20 - n];
         }
-        const f2 Bev = (f2){br[0] + br[10], bi[0] + bi[10]}, Bod = (f2){br[0] - br[10], bi[0] - bi[10]};
-        float xr[11], xi[11];
+        const f2 Bev = B[0] + B[10], Bod = B[0] - B[10];
+        float pk2[11];
 #define WT_MAC2(acc, x, w)                                                          \
     do {                                                                            \
         constexpr float _w = (w);                                                   \
@@ -262,31 +270,28 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     } while (0)
 #define WT_S2(K)                                                                                              \
         {                                                                                                     \
-            f2 CDe = {0.f, 0.f}, CDo = {0.f, 0.f}, STe = {0.f, 0.f}, STo = {0.f, 0.f};                        \
+            f2 CDe = {0.f, 0.f}, CDo = {0.f, 0.f}, SDe = {0.f, 0.f}, SDo = {0.f, 0.f};                        \
             WT_MAC2(CDe, P[2], c20(2 * K)); WT_MAC2(CDe, P[4], c20(4 * K)); WT_MAC2(CDe, P[6], c20(6 * K));   \
             WT_MAC2(CDe, P[8], c20(8 * K));                                                                   \
             WT_MAC2(CDo, P[1], c20(1 * K)); WT_MAC2(CDo, P[3], c20(3 * K)); WT_MAC2(CDo, P[5], c20(5 * K));   \
             WT_MAC2(CDo, P[7], c20(7 * K)); WT_MAC2(CDo, P[9], c20(9 * K));                                   \
-            WT_MAC2(STe, Ms[2], s20(2 * K)); WT_MAC2(STe, Ms[4], s20(4 * K)); WT_MAC2(STe, Ms[6], s20(6 * K)); \
-            WT_MAC2(STe, Ms[8], s20(8 * K));                                                                  \
-            WT_MAC2(STo, Ms[1], s20(1 * K)); WT_MAC2(STo, Ms[3], s20(3 * K)); WT_MAC2(STo, Ms[5], s20(5 * K)); \
-            WT_MAC2(STo, Ms[7], s20(7 * K)); WT_MAC2(STo, Ms[9], s20(9 * K));                                 \
+            WT_MAC2(SDe, D[2], s20(2 * K)); WT_MAC2(SDe, D[4], s20(4 * K)); WT_MAC2(SDe, D[6], s20(6 * K));   \
+            WT_MAC2(SDe, D[8], s20(8 * K));                                                                   \
+            WT_MAC2(SDo, D[1], s20(1 * K)); WT_MAC2(SDo, D[3], s20(3 * K)); WT_MAC2(SDo, D[5], s20(5 * K));   \
+            WT_MAC2(SDo, D[7], s20(7 * K)); WT_MAC2(SDo, D[9], s20(9 * K));                                   \
             const f2 Bk = (K & 1) ? Bod : Bev;                                                                \
-            const f2 X0 = Bk + (CDe + CDo) + (STe + STo), X1 = Bk + (CDe - CDo) + (STo - STe);                \
-            xr[K] = X0.x; xi[K] = X0.y; xr[10 - K] = X1.x; xi[10 - K] = X1.y;                                 \
+            const f2 U0 = Bk + (CDe + CDo), V0 = SDe + SDo, U1 = Bk + (CDe - CDo), V1 = SDo - SDe;            \
+            const float r0 = U0.x + V0.y, i0 = U0.y - V0.x, r1 = U1.x + V1.y, i1 = U1.y - V1.x;              \
+            /* |X|^2 directly: torch's stft.abs() ** 2 rounds through a square root, which moves the power by */ \
+            /* <= 2 ulp (1e-7 of a log-mel value) and costs an IEEE sqrt per bin */                            \
+            pk2[K] = r0 * r0 + i0 * i0; pk2[10 - K] = r1 * r1 + i1 * i1;                                      \
         }
         WT_S2(0) WT_S2(1) WT_S2(2) WT_S2(3) WT_S2(4) WT_S2(5)
 #undef WT_S2
 #undef WT_MAC2
 #pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2) {
-            // |X|^2 directly: torch's stft.abs() ** 2 rounds through a square root, which moves the power by <= 2 ulp
-            // (1e-7 of a log-mel value) and costs an IEEE sqrt per bin
-            pw[slot][u + 20 * k2] = xr[k2] * xr[k2] + xi[k2] * xi[k2];
-        }
-        if (u == 0) {  // k = 200 (k1 = 0, k2 = 10)
-            pw[slot][200] = xr[10] * xr[10] + xi[10] * xi[10];
-        }
+        for (int k2 = 0; k2 < 10; ++k2) pw[slot][u + 20 * k2] = pk2[k2];
+        if (u == 0) pw[slot][200] = pk2[10];   // k = 200 (k1 = 0, k2 = 10)
     }
     __syncthreads();
 
