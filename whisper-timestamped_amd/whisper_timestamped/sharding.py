@@ -170,9 +170,12 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
 
     Not the reference's `vad=` mode (that one glues the islands and decodes them as ONE stream, which cannot be split
     without changing what the decoder is conditioned on); per island the results are the reference's.
-    `audio`: 1-D float tensor on rank 0 (None elsewhere -> broadcast) or on every rank.  `on_island(i)` is called
+    `audio`: what transcribe() accepts (path, ndarray, 1-D tensor), on rank 0 (None elsewhere -> broadcast) or on every rank.  `on_island(i)` is called
     before island i is transcribed (progress / test scripting).  `options` go to transcribe_timestamped()."""
+    from .naive import get_audio_tensor
     from .transcribe import transcribe_timestamped
+    if audio is not None:
+        audio = get_audio_tensor(audio)            # a path, an ndarray or a tensor, like transcribe()
     rank = 0 if dist is None else dist.get_rank()
     world = 1 if dist is None else dist.get_world_size()
     islands = [(float(s), float(e)) for s, e in islands]
