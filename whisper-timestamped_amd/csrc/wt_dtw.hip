@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
         constexpr bool EDGE = decltype(edge_c)::value, PUBLISH = decltype(publish_c)::value;
         auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
             if (TINY) load_blk_tiny(unit, i, s0 + BLK - lane, T, F, nxt);
-            else load_blk(ubuf, boff0 + 4 * (s0 + BLK), nxt);  // prefetch the next block (~2k cycles ahead)
+            else {
+                int vo = boff0 + 4 * (s0 + BLK);
+                asm volatile("" : "+v"(vo));  // ONE address per block + immediate offsets (hipcc otherwise keeps 8 induction adds)
+                load_blk(ubuf, vo, nxt);      // prefetch the next block (~2k cycles ahead)
+            }
             // the loads stay HERE, a whole block ahead of their first use (without this fence hipcc rotates the loop
             // and sinks them to just before the use: the memory latency is then exposed once per iteration; `cost`
             // is deliberately not __restrict__: loads the compiler knows to be invariant ignore the fence)
