@@ -233,7 +233,7 @@ def run_step(w, ev=None, streams=None):
     calls = w.setdefault("_calls", _stage_calls(w))
     main = torch.cuda.current_stream()
     if isinstance(streams, tuple) and streams[0] == "dtw_logmel":
-        # cost -> [DTW on a side stream: 32 CUs, 137 KB of LDS each, latency-bound] || [log-mel: VALU-bound, fills
+        # cost -> [DTW on a side stream: 32 CUs, 141 KB of LDS each, latency-bound] || [log-mel: VALU-bound, fills
         # the other 224 CUs; its workgroups do not fit next to a DTW workgroup] -> log-prob alone (HBM-bound)
         side = streams[1]
         if ev: ev["cost"][0].record(main)
