@@ -17,7 +17,7 @@
 // two stages goes through LDS.  Three frames per wave, twelve per 256-thread
 // workgroup (39 KB of LDS: 16 waves per CU), 250 workgroups per 30 s chunk.
 // ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT; the kernel is
-// VALU-issue bound (profiles/r1l_sq_counters.txt).
+// VALU-issue bound (profiles/r1r_sq_counters.txt).
 // Pass 1 writes log10(mel) and one maximum per workgroup (no atomics, nothing
 // to reset); pass 2 reduces them per chunk, applies the clamp/scale and the
 // zero padding.  Algorithmic bytes: 480000*4 read + n_mels*3000*4 written per
