@@ -193,6 +193,8 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.wt_logprob_gather_batch(p, 0, 100, 0, 100, p, 0, 0, p, 0) == 0
     assert L.wt_capture_rows(p, 0, 6, 1, 1500, p, p, 2, p, 0, 16, 16, 0) == -1 and b"row=16 of 16" in L.wt_last_error()
     assert L.wt_find_start_padding_batch(p, 1, 80, 1, p, 0) == -1
+    assert L.wt_disfluency_batch(p, p, 1, 0, p, 0.02, 3.0, 0) == -1 and b"wt_disfluency_batch" in L.wt_last_error()
+    assert L.wt_disfluency_batch(p, p, 0, p, p, 0.02, 3.0, 0) == 0                     # no units: nothing to do
     assert L.wt_logmel_batch(p, 1, 100, 0, p, 80, 3000, p, 0, 0) == -1                 # fewer than 201 samples
     assert L.wt_shutdown() == 0
 
