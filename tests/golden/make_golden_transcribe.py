@@ -186,6 +186,18 @@ def case_list():
     C.append(dict(name="naive_language_detection", model="tiny", audio_s=8.0, audio_seed=17,
                   opts=dict(language=None, temperature=(0.0, 0.4)),
                   script=[window_script(ML, EOT_ML, [seg(32, 6, 7, 330)], "eot")]))
+    C.append(dict(name="naive_vad_islands", model="tiny", audio_s=28.0, audio_seed=28,
+                  opts=dict(language="en", naive_approach=True, vad=[(1.0, 8.25), (12.5, 19.0)]),
+                  script=[window_script(ML, EOT_ML, [seg(74, 4, 7, 300), seg(75, 320, 8, 660)], "eot")]))
+    C.append(dict(name="naive_disfluencies_punctuation", model="tiny", audio_s=15.0, audio_seed=29,
+                  opts=dict(language="en", naive_approach=True, detect_disfluencies=True, remove_punctuation_from_words=True,
+                            min_word_duration=0.06),
+                  script=[window_script(ML, EOT_ML, [(3, [6455, 11, 2232, 286, 13, 2041, 8660], 380),
+                                                     seg(76, 400, 11, 730)], "eot")]))
+    C.append(dict(name="naive_two_windows_prompted", model="tiny", audio_s=43.0, audio_seed=30,
+                  opts=dict(language="en", naive_approach=True, initial_prompt="Well then"),
+                  script=[window_script(ML, EOT_ML, [seg(77, 0, 7, 350), seg(78, 360, 6, 820), seg(79, 840, 8, 1380)], "pair"),
+                          window_script(ML, EOT_ML, [seg(80, 12, 7, 420)], "eot")]))
     return C
 
 
