@@ -427,6 +427,9 @@ def test_reference_side_stub():
     got_cost = cost.cpu().numpy().reshape(T, end - start)
     np.testing.assert_allclose(got_cost, want_cost, rtol=2e-5, atol=2e-7)
     assert np.abs(jumps.astype(np.int64) - want).max() <= 1
+    jumps2, _, starts = ns["_wt_jumps"](torch.from_numpy(qk).to(DEV), start, end, mask.to_sparse(), max_duration, True)
+    assert np.array_equal(jumps2, jumps)
+    assert np.array_equal(starts.astype(np.int64), O.jumps_start_ref(got_cost, jumps.astype(np.int64)))
 
 
 def test_disfluency_kernel_vs_scipy():
