@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 1
+#define WT_ABI_VERSION 2 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows */
 
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
@@ -43,6 +43,7 @@ extern "C" {
 #define WT_N_AUDIO_CTX 1500 /* frames of 20 ms per 30 s window (T.py:44-47)       */
 #define WT_MAX_TOKENS 256   /* rows of one DTW (decoder emits <= 224 + 2)         */
 #define WT_MAX_FRAMES 1792
+#define WT_MAX_LAYERS 32    /* hooked decoder layers of one wt_qk_rows_batch call     */
 
 /* One alignment unit = one call of perform_word_alignment (T.py:1428): a
  * (heads, T tokens, F frames) window of cross-attention QK logits.
@@ -91,6 +92,24 @@ int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ct
 int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int d_model, int head_dim, float scale,
                const int32_t *heads, const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows,
                int64_t row0, void *stream);
+
+/* wt_qk_rows for a BATCH of independent 30 s windows and ALL hooked decoder layers in one launch: the batched
+ * form of the naive strategy's teacher-forced re-run (T.py:1110-1121 hook, 1236-1249 forward + slice), where the
+ * reference runs one window at a time.  For window b, selected head i (layer sel_layer[i], head sel_head[i]) and
+ * query row r in [row_begin[b], row_end[b]):
+ *     ring[b][sel_slot[i]][ring_row0 + r][f] = sum_d (q_l[b][r][h*hd+d] * s) * (k_l[b][f][h*hd+d] * s)
+ *   q_layers_host / k_layers_host : HOST arrays of n_layers (<= WT_MAX_LAYERS) DEVICE pointers: cross_attn.query
+ *                                   output (n_batch, n_q, d_model) and cross_attn.key output (n_batch, n_ctx, d_model)
+ *                                   of each hooked layer; batch strides in elements; rows contiguous (d_model)
+ *   sel_layer/sel_head/sel_slot   : device int32[n_sel]
+ *   row_begin/row_end             : device int32[n_batch] or NULL (= all n_q rows)
+ *   ring                          : device [n_batch][n_slots][ring_rows][n_ctx] (ring_batch_stride elements per window)
+ * head_dim must be 64 (every Whisper checkpoint).  Arithmetic identical to wt_qk_rows. */
+int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,
+                     int n_q, int64_t q_batch_stride, int64_t k_batch_stride, int n_ctx, int d_model, int head_dim,
+                     float scale, const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
+                     const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_batch_stride,
+                     int64_t ring_rows, int64_t ring_row0, void *stream);
 
 /* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
  * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,
@@ -149,6 +168,12 @@ int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int 
  *   suppress_rows : 0 = none, 1 = one shared mask row, n_rows = per-row masks */
 int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
                             const int32_t *token, const uint8_t *suppress, int suppress_rows, float *out, void *stream);
+
+/* The same gather with an explicit row list: out[r] = log_softmax(logits row row_index[r])[token[r]], r < n_out.
+ * Rows may repeat or be skipped: T.py:1292 `logprobs[:, step, tok]` for the text positions of many teacher-forced
+ * windows at once, read from one padded (n_windows * T_max, V) logits block (no logit filters on this path, T.py:1245). */
+int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_stride, const int32_t *row_index, int n_out,
+                           int V, const int32_t *token, float *out, void *stream);
 
 /* openai-whisper audio.log_mel_spectrogram + pad_or_trim as called at
  * T.py:1213-1214 (naive path; n_frames = 3000) for a batch of equal-length

@@ -52,15 +52,48 @@ def install(monkeypatch):
         return mel, gmax
     monkeypatch.setattr(_lib, "logmel", logmel)
 
-    def run(self):
+    def launch(self):
+        self._launched = True
+        self.extra = torch.zeros(self.extra_words, dtype=torch.int32) if self.extra_words else None
+        return self
+
+    def fetch(self):
+        if not self._launched:
+            self.launch()
+        return self
+
+    def collect(self):
+        self.fetch()
         out = []
         for u in self.units:
-            sel = u.qk[:, :, u.start_token:u.end_token].contiguous().numpy()
+            sel = u.qk[:, :, u.start_token:u.end_token].contiguous().float().numpy()
             pad = u.pad_from if u.pad_from >= 0 else None
             cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
             r = O.dtw_ref(cost)
             jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
             starts = O.jumps_start_ref(cost, jumps) if u.detect_disfluencies else None
             out.append(alignment.finish_unit(u, jumps, starts))
+        self.extra_host = self.extra.numpy() if self.extra is not None else None
         return out
-    monkeypatch.setattr(alignment.AlignmentBatch, "run", run)
+    monkeypatch.setattr(alignment.AlignmentBatch, "launch", launch)
+    monkeypatch.setattr(alignment.AlignmentBatch, "fetch", fetch)
+    monkeypatch.setattr(alignment.AlignmentBatch, "collect", collect)
+
+    # batched naive strategy (whisper_timestamped/batched.py)
+    def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring, row_begin=None, row_end=None, ring_row0=0):
+        B, n_q, D = q_layers[0].shape
+        hd = 64
+        scale = hd ** -0.25
+        for l, h, s in zip(sel_layer.tolist(), sel_head.tolist(), sel_slot.tolist()):
+            q = (q_layers[l][:, :, h * hd:(h + 1) * hd] * scale)
+            k = (k_layers[l][:, :, h * hd:(h + 1) * hd] * scale)
+            ring[:, s, ring_row0:ring_row0 + n_q] = (q @ k.transpose(1, 2)).float().to(ring.dtype)
+    monkeypatch.setattr(_lib, "qk_rows_batch", qk_rows_batch)
+
+    def logprob_gather_rows(logits, row_index, tokens, out=None):
+        lp = O.token_logprob_gather_ref(logits[row_index.long()].float(), tokens.numpy().astype(np.int64))
+        if out is None:
+            return lp
+        out[:lp.numel()].copy_(lp)
+        return out
+    monkeypatch.setattr(_lib, "logprob_gather_rows", logprob_gather_rows)

@@ -198,6 +198,30 @@ def case_list():
                   opts=dict(language="en", naive_approach=True, initial_prompt="Well then"),
                   script=[window_script(ML, EOT_ML, [seg(77, 0, 7, 350), seg(78, 360, 6, 820), seg(79, 840, 8, 1380)], "pair"),
                           window_script(ML, EOT_ML, [seg(80, 12, 7, 420)], "eot")]))
+    # ---- naive strategy, trust_whisper_timestamps=False over SEVERAL windows: the 30 s seek groups are independent
+    #      (transcribe.py:1197-1202), which is what whisper_timestamped/batched.py runs as one batch -----------------
+    C.append(dict(name="naive_no_trust_three_windows", model="tiny", audio_s=75.0, audio_seed=31,
+                  opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False),
+                  script=[window_script(ML, EOT_ML, [seg(81, 0, 8, 420), seg(82, 440, 7, 900), seg(83, 920, 6, 1400)], "pair"),
+                          window_script(ML, EOT_ML, [seg(84, 10, 9, 600), seg(85, 620, 5, 1250)], "pair"),
+                          window_script(ML, EOT_ML, [seg(86, 20, 7, 500)], "eot")]))
+    C.append(dict(name="naive_no_trust_beam_two_windows", model="tiny", audio_s=52.0, audio_seed=32,
+                  opts=dict(language="en", beam_size=2, trust_whisper_timestamps=False, include_punctuation_in_confidence=True),
+                  script=[window_script(ML, EOT_ML, [seg(87, 0, 6, 500), (520, [6455, 11, 2232, 286, 13], 1100)], "pair"),
+                          window_script(ML, EOT_ML, [seg(89, 15, 8, 700)], "eot")]))
+    C.append(dict(name="naive_no_trust_disfluencies_padding", model="tiny", audio_s=37.0, audio_seed=33,
+                  opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False, detect_disfluencies=True,
+                            remove_punctuation_from_words=True, refine_whisper_precision=0.2),
+                  script=[window_script(ML, EOT_ML, [(3, [6455, 11, 2232, 286, 13, 2041, 8660], 380),
+                                                     seg(90, 400, 11, 930), seg(91, 950, 6, 1450)], "pair"),
+                          window_script(ML, EOT_ML, [seg(92, 5, 7, 300)], "noend")]))
+    C.append(dict(name="naive_no_trust_english_only_four_windows", model="tiny.en", audio_s=100.0, audio_seed=34,
+                  opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False, compute_word_confidence=True,
+                            condition_on_previous_text=False),
+                  script=[window_script(EN, EOT_EN, [seg(93, 0, 7, 700), seg(94, 720, 8, 1490)], "pair"),
+                          window_script(EN, EOT_EN, [seg(95, 0, 6, 800)], "pair"),
+                          window_script(EN, EOT_EN, [seg(96, 30, 9, 600), seg(97, 610, 6, 1300)], "pair"),
+                          window_script(EN, EOT_EN, [seg(98, 10, 5, 350)], "eot")]))
     return C
 
 

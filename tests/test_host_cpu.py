@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.wt_version.restype = ctypes.c_int
-    assert L.wt_version() == 1
+    assert L.wt_version() == _lib.ABI_VERSION == 2
 
 
 def test_seg_desc_layout_matches_header():
@@ -196,6 +196,17 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.wt_disfluency_batch(p, p, 1, 0, p, 0.02, 3.0, 0) == -1 and b"wt_disfluency_batch" in L.wt_last_error()
     assert L.wt_disfluency_batch(p, p, 0, p, p, 0.02, 3.0, 0) == 0                     # no units: nothing to do
     assert L.wt_logmel_batch(p, 1, 100, 0, p, 80, 3000, p, 0, 0) == -1                 # fewer than 201 samples
+    descs[0]["T"], descs[0]["F"] = 300, 1500                                           # colnorm covers 256 token rows
+    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 9, 1.0, p, 0) == -3 and b"T=300" in L.wt_last_error()
+    assert L.wt_logprob_gather_rows(p, 0, 100, 0, 4, 100, p, p, 0) == -1 and b"row_index" in L.wt_last_error()
+    assert L.wt_logprob_gather_rows(p, 0, 100, p, 0, 100, p, p, 0) == 0                # no rows: nothing to do
+    import ctypes as C
+    ptrs = (C.c_void_p * 2)(p, p)
+    args = lambda n_layers, hd, row0: (ptrs, ptrs, n_layers, 0, 2, 10, 5120, 768000, 1500, 512, hd, 0.35, p, p, p, 8, 0, 0, p,
+                                       0, 8 * 16 * 1500, 16, row0, 0)   # noqa: E731
+    assert L.wt_qk_rows_batch(*args(40, 64, 0)) == -1 and b"40 layers" in L.wt_last_error()
+    assert L.wt_qk_rows_batch(*args(2, 64, 8)) == -1 and b"rows 8..18 of 16" in L.wt_last_error()
+    assert L.wt_qk_rows_batch(*args(2, 32, 0)) == -3 and b"head_dim=32" in L.wt_last_error()
     assert L.wt_shutdown() == 0
 
 

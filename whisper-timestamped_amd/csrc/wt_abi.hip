@@ -80,7 +80,11 @@ int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int,
                hipStream_t);
 int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int32_t *, int32_t *, int32_t *, int32_t *,
               double *, hipStream_t);
-int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, float *, hipStream_t);
+int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
+                         hipStream_t);
+int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, int64_t, int64_t, int, int, int, float,
+                  const int32_t *, const int32_t *, const int32_t *, int, const int32_t *, const int32_t *, void *, int, int64_t,
+                  int64_t, int64_t, hipStream_t);
 int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
 int disfluency_batch(const float *, const wt_seg_desc *, int, const int32_t *, int32_t *, double, double, hipStream_t);
 int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
@@ -156,8 +160,28 @@ int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int 
 
 int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
                             const int32_t *token, const uint8_t *suppress, int suppress_rows, float *out, void *stream) {
-    return wt::logprob_gather_batch(logits, logits_dtype, row_stride, n_rows, V, token, suppress, suppress_rows, out,
+    return wt::logprob_gather_batch(logits, logits_dtype, row_stride, n_rows, V, token, suppress, suppress_rows, nullptr, out,
                                     (hipStream_t)stream);
+}
+
+int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_stride, const int32_t *row_index, int n_out,
+                           int V, const int32_t *token, float *out, void *stream) {
+    if (!row_index) {
+        wt::set_error("wt_logprob_gather_rows: row_index is null");
+        return WT_E_BADARG;
+    }
+    return wt::logprob_gather_batch(logits, logits_dtype, row_stride, n_out, V, token, nullptr, 0, row_index, out,
+                                    (hipStream_t)stream);
+}
+
+int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,
+                     int n_q, int64_t q_batch_stride, int64_t k_batch_stride, int n_ctx, int d_model, int head_dim,
+                     float scale, const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
+                     const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_batch_stride,
+                     int64_t ring_rows, int64_t ring_row0, void *stream) {
+    return wt::qk_rows_batch(q_layers_host, k_layers_host, n_layers, dtype, n_batch, n_q, q_batch_stride, k_batch_stride, n_ctx,
+                             d_model, head_dim, scale, sel_layer, sel_head, sel_slot, n_sel, row_begin, row_end, ring,
+                             ring_dtype, ring_batch_stride, ring_rows, ring_row0, (hipStream_t)stream);
 }
 
 int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,

@@ -121,4 +121,112 @@ int qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int 
     return WT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same rows for a BATCH of windows and ALL hooked layers in one launch (the batched naive strategy: B
+// independent 30 s windows teacher-forced through the decoder at once).  Per (window b, selected head s) the work
+// is a small GEMM  Q_b[rows, hd] x K_b[n_ctx, hd]^T: one thread owns one frame f, keeps K_b[f, h*hd .. +hd) -- scaled
+// once -- in registers and walks the query rows, which the workgroup stages (scaled) in LDS and reads back with
+// broadcast ds_read_b128: K crosses L2 once per (window, head) instead of once per query row, the stores of a row
+// are coalesced over f.  Same arithmetic as qk_rows_kernel (sequential fma over the head dimension), so the rows
+// are bit-identical to the single-window entry.  Rows outside [row_begin[b], row_end[b]) -- prompt rows nobody
+// aligns, padding of shorter transcripts -- are skipped.
+struct QkLayers {
+    const void *q[WT_MAX_LAYERS];
+    const void *k[WT_MAX_LAYERS];
+};
+
+constexpr int QB_ROWS = 32;   // query rows staged per trip
+
+template <typename T, typename DT, int HD>
+__global__ __launch_bounds__(256) void qk_rows_batch_kernel(QkLayers L, int n_q, int64_t q_bstride, int64_t k_bstride, int n_ctx,
+                                                            int d_model, float scale, const int32_t *__restrict__ sel_layer,
+                                                            const int32_t *__restrict__ sel_head,
+                                                            const int32_t *__restrict__ sel_slot,
+                                                            const int32_t *__restrict__ row_begin,
+                                                            const int32_t *__restrict__ row_end, DT *__restrict__ ring,
+                                                            int64_t ring_bstride, int64_t ring_rows, int64_t ring_row0) {
+    __shared__ __attribute__((aligned(16))) float qs[QB_ROWS][HD];
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int layer = sel_layer[s], h = sel_head[s];
+    const int r_lo = row_begin ? max(row_begin[b], 0) : 0;
+    const int r_hi = row_end ? min(row_end[b], n_q) : n_q;
+    if (r_lo >= r_hi) return;   // block-uniform
+    const T *q = static_cast<const T *>(L.q[layer]) + (int64_t)b * q_bstride + (int64_t)h * HD;
+    const T *k = static_cast<const T *>(L.k[layer]) + (int64_t)b * k_bstride + (int64_t)h * HD;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool f_ok = f < n_ctx;
+    float kr[HD];
+    {
+        const T *krow = k + (int64_t)min(f, n_ctx - 1) * d_model;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) kr[d] = scaled<T>(krow[d], scale);
+    }
+    DT *out = ring + (int64_t)b * ring_bstride + ((int64_t)sel_slot[s] * ring_rows + ring_row0) * n_ctx + f;
+    for (int r0 = r_lo; r0 < r_hi; r0 += QB_ROWS) {
+        const int nr = min(QB_ROWS, r_hi - r0);
+        __syncthreads();   // the previous trip's readers are done
+        for (int e = threadIdx.x; e < nr * HD; e += 256) {
+            const int r = e / HD, d = e % HD;
+            qs[r][d] = scaled<T>(q[(int64_t)(r0 + r) * d_model + d], scale);
+        }
+        __syncthreads();
+        for (int r = 0; r < nr; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 qv = *reinterpret_cast<const float4 *>(&qs[r][d]);
+                acc = fmaf(qv.x, kr[d], acc);
+                acc = fmaf(qv.y, kr[d + 1], acc);
+                acc = fmaf(qv.z, kr[d + 2], acc);
+                acc = fmaf(qv.w, kr[d + 3], acc);
+            }
+            if (sizeof(T) == 2) acc = __half2float(__float2half(acc));
+            if (f_ok) out[(int64_t)(r0 + r) * n_ctx] = cvt<float, DT>(acc);
+        }
+    }
+}
+
+int qk_rows_batch(const void *const *q_layers, const void *const *k_layers, int n_layers, int dtype, int n_batch, int n_q,
+                  int64_t q_bstride, int64_t k_bstride, int n_ctx, int d_model, int head_dim, float scale,
+                  const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
+                  const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_bstride,
+                  int64_t ring_rows, int64_t ring_row0, hipStream_t st) {
+    if (!q_layers || !k_layers || n_layers <= 0 || n_layers > WT_MAX_LAYERS || !sel_layer || !sel_head || !sel_slot || !ring ||
+        n_batch < 0 || n_q <= 0 || n_ctx <= 0 || d_model <= 0 || head_dim <= 0 || d_model % head_dim != 0 || n_sel < 0 ||
+        ring_row0 < 0 || ring_row0 + n_q > ring_rows) {
+        set_error("wt_qk_rows_batch: bad argument (%d layers, rows %lld..%lld of %lld)", n_layers, (long long)ring_row0,
+                  (long long)(ring_row0 + n_q), (long long)ring_rows);
+        return WT_E_BADARG;
+    }
+    if (head_dim != 64) {   // every Whisper checkpoint has 64-wide heads (n_state / 64 heads)
+        set_error("wt_qk_rows_batch: head_dim=%d unsupported (Whisper heads are 64 wide)", head_dim);
+        return WT_E_UNSUPPORTED;
+    }
+    if (n_sel == 0 || n_batch == 0) return WT_OK;
+    QkLayers L = {};
+    for (int l = 0; l < n_layers; ++l) {
+        if (!q_layers[l] || !k_layers[l]) {
+            set_error("wt_qk_rows_batch: layer %d has a null projection", l);
+            return WT_E_BADARG;
+        }
+        L.q[l] = q_layers[l];
+        L.k[l] = k_layers[l];
+    }
+    const dim3 grid((n_ctx + 255) / 256, n_sel, n_batch), block(256);
+#define WT_QKB(ST, DT)                                                                                                   \
+    hipLaunchKernelGGL((qk_rows_batch_kernel<ST, DT, 64>), grid, block, 0, st, L, n_q, q_bstride, k_bstride, n_ctx, d_model, \
+                       scale, sel_layer, sel_head, sel_slot, row_begin, row_end, (DT *)ring, ring_bstride, ring_rows, ring_row0)
+    if (dtype == WT_DTYPE_F32 && ring_dtype == WT_DTYPE_F32) WT_QKB(float, float);
+    else if (dtype == WT_DTYPE_F32 && ring_dtype == WT_DTYPE_F16) WT_QKB(float, __half);
+    else if (dtype == WT_DTYPE_F16 && ring_dtype == WT_DTYPE_F32) WT_QKB(__half, float);
+    else if (dtype == WT_DTYPE_F16 && ring_dtype == WT_DTYPE_F16) WT_QKB(__half, __half);
+    else {
+        set_error("wt_qk_rows_batch: dtype %d -> %d", dtype, ring_dtype);
+        return WT_E_BADARG;
+    }
+#undef WT_QKB
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
 }  // namespace wt

@@ -369,7 +369,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     int maxF = 0;
     for (int i = 0; i < n_seg; ++i) {
         const wt_seg_desc &d = segs_host[i];
-        if (d.T < 1 || d.F < 1 || d.F > WT_MAX_FRAMES || d.start_token < 0) {
+        if (d.T < 1 || d.T > WT_MAX_TOKENS || d.F < 1 || d.F > WT_MAX_FRAMES || d.start_token < 0) {   // (colnorm covers 256 rows)
             set_error("wt_cost_batch: unit %d has unsupported shape T=%d F=%d start=%d", i, d.T, d.F, d.start_token);
             return WT_E_UNSUPPORTED;
         }

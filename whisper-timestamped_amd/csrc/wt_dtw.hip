@@ -103,7 +103,10 @@ __device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1
 // boundary row, the other lanes' pointers sit in a 64+32-double parking area (distinct addresses: no bank
 // conflict, no exec juggling) -- one ds_write per step instead of a 4-DPP cross-lane shift register.
 // u0/u1 alternate as "g[i-1,j]" and "g[i-1,j-1]" so that no register is copied.
-template <bool EDGE, bool PUBLISH, bool DIST>
+// FIRST: the block that holds step 0 on the first wave.  Cell (0,0) is seeded through lane 0's `diag` (u1 = 0.0, so
+// that p1 = 0 + lm[0,0] = cm[0,0] as in computeCM); wave_shr:1 never overwrites lane 0, so that seed must be
+// retired to +inf before u1 comes back as "g[-1, 1]" at step 1 -- two moves, once per unit, none in the steady loop.
+template <bool EDGE, bool PUBLISH, bool DIST, bool FIRST = false>
 __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1,
                                             const double (&edge)[BLK], uint32_t &wa, uint32_t &wb, double *pub, int s0,
                                             int sfinal, double &gfinal) {
@@ -111,6 +114,7 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
     for (int k = 0; k < BLK; ++k) {
         double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
         const double diag = (k & 1) ? u0 : u1;   // g[i-1, j-1] (written one step ago)
+        if (FIRST && k == 1) u1 = __builtin_inf();   // (lanes > 0 receive their neighbour's g just below)
         if (EDGE) up = wave_shr1(g, edge[k]);    // lane 0 <- edge value of this step, lane l <- g of lane l-1
         else shift_in(up, g);                    // lane 0 keeps its +inf
         const double c = (double)cur[k];
@@ -174,12 +178,15 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     const int pubinc = (lane == 63) ? BLK : 0;
     const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
 
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
     // The role of a wave (has a producer above / a consumer below) is decided ONCE, outside the sweep: each role runs
     // its own loop, so a block costs one taken branch instead of a chain of exec-masked skips over the other roles'
     // code (a taken branch is ~20 cycles for a lone wave, a skipped one ~11; measured ~15 cycles per step overall).
     auto sweep = [&](auto edge_c, auto publish_c) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(edge_c)::value, PUBLISH = decltype(publish_c)::value;
-        auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0) __attribute__((always_inline)) {
+        auto block = [&](const float (&cur)[BLK], float (&nxt)[BLK], int s0, auto first_c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
             if (TINY) load_blk_tiny(unit, i, s0 + BLK - lane, T, F, nxt);
             else {
                 int vo = boff0 + 4 * (s0 + BLK);
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                     edge[2 * k + 1] = v.y;
                 }
             }
-            sweep_block<EDGE, PUBLISH, DIST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
+            sweep_block<EDGE, PUBLISH, DIST, FIRST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
             plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
             if (PUBLISH) {
                 pub += pubinc;
@@ -215,13 +222,14 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                 }
             }
         };
-        for (int s0 = 0; s0 < nsteps; s0 += 2 * BLK) {
-            block(bufA, bufB, s0);
-            if (s0 + BLK < nsteps) block(bufB, bufA, s0 + BLK);
+        // (the first wave's first block is its own instantiation: see FIRST above; nsteps >= 64 = 2 blocks)
+        block(bufA, bufB, 0, std::integral_constant<bool, !EDGE>{});
+        block(bufB, bufA, BLK, no{});
+        for (int s0 = 2 * BLK; s0 < nsteps; s0 += 2 * BLK) {
+            block(bufA, bufB, s0, no{});
+            if (s0 + BLK < nsteps) block(bufB, bufA, s0 + BLK, no{});
         }
     };
-    using yes = std::integral_constant<bool, true>;
-    using no = std::integral_constant<bool, false>;
     if (wave == 0) {
         if (producer) sweep(no{}, yes{}); else sweep(no{}, no{});
     } else {

@@ -56,8 +56,9 @@ template <typename LT>
 __global__ __launch_bounds__(256) void logprob_gather_kernel(const LT *__restrict__ logits, int64_t row_stride, int V,
                                                              const int32_t *__restrict__ token,
                                                              const uint8_t *__restrict__ suppress, int suppress_rows,
+                                                             const int32_t *__restrict__ row_index,
                                                              float *__restrict__ out) {
-    const int row = blockIdx.x;
+    const int row = row_index ? row_index[blockIdx.x] : blockIdx.x;   // which logits row this output reads
     const LT *x = logits + (int64_t)row * row_stride;
     const uint8_t *sup = suppress ? suppress + (suppress_rows > 1 ? (int64_t)row * V : 0) : nullptr;
     const int tid = threadIdx.x;
@@ -139,17 +140,20 @@ __global__ __launch_bounds__(256) void logprob_gather_kernel(const LT *__restric
     __syncthreads();
     if (tid == 0) {
         MS t = ms_merge(ms_merge(part[0], part[1]), ms_merge(part[2], part[3]));
-        const int tok = token[row];
+        const int tok = token[blockIdx.x];
         float xt = -INFINITY;
         if (tok >= 0 && tok < V && !(sup && sup[tok])) xt = ldf(x + tok);
-        out[row] = (xt - t.m) - logf(t.s);
+        out[blockIdx.x] = (xt - t.m) - logf(t.s);
     }
 }
 
+// row_index (optional): output r reads logits row row_index[r] (rows may repeat or be skipped: the batched naive
+// strategy gathers the text positions of many padded windows from one (B*T_max, V) block); per-row suppress masks
+// are then indexed by the logits row as well.
 int logprob_gather_batch(const void *logits, int dtype, int64_t row_stride, int n_rows, int V, const int32_t *token,
-                         const uint8_t *suppress, int suppress_rows, float *out, hipStream_t st) {
+                         const uint8_t *suppress, int suppress_rows, const int32_t *row_index, float *out, hipStream_t st) {
     if (!logits || !token || !out || n_rows < 0 || V <= 0 || row_stride < V ||
-        (suppress && suppress_rows != 1 && suppress_rows != n_rows)) {
+        (suppress && suppress_rows != 1 && suppress_rows != n_rows && !row_index)) {
         set_error("wt_logprob_gather_batch: bad argument");
         return WT_E_BADARG;
     }
@@ -157,10 +161,10 @@ int logprob_gather_batch(const void *logits, int dtype, int64_t row_stride, int 
     const uint8_t *sup = suppress_rows > 0 ? suppress : nullptr;
     if (dtype == WT_DTYPE_F32)
         hipLaunchKernelGGL(logprob_gather_kernel<float>, dim3(n_rows), dim3(256), 0, st, (const float *)logits, row_stride, V,
-                           token, sup, suppress_rows, out);
+                           token, sup, suppress_rows, row_index, out);
     else if (dtype == WT_DTYPE_F16)
         hipLaunchKernelGGL(logprob_gather_kernel<__half>, dim3(n_rows), dim3(256), 0, st, (const __half *)logits, row_stride,
-                           V, token, sup, suppress_rows, out);
+                           V, token, sup, suppress_rows, row_index, out);
     else {
         set_error("wt_logprob_gather_batch: dtype=%d", dtype);
         return WT_E_BADARG;

@@ -28,7 +28,8 @@ assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
-           "wt_disfluency_batch"]
+           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows"]
+ABI_VERSION = 2
 
 
 class WtError(RuntimeError):
@@ -60,6 +61,12 @@ def load():
     L.wt_logmel_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp]
     L.wt_capture_rows.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i64, i64, vp]
     L.wt_qk_rows.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, i64, i64, vp]
+    L.wt_qk_rows_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, f32, vp, vp, vp, i32, vp, vp, vp, i32, i64,
+                                   i64, i64, vp]
+    L.wt_logprob_gather_rows.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp]
+    if L.wt_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} exports ABI version {L.wt_version()}, this package needs {ABI_VERSION}: rebuild it "
+                          f"(`make -C {_PKG_ROOT}/csrc`)")
     for n in EXPORTS[3:]:
         getattr(L, n).restype = i32
     _lib = L
@@ -72,8 +79,70 @@ def _check(rc: int, what: str):
         raise WtError(f"{what} failed (rc={rc}): {msg}")
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    """Current torch stream of `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """``with on_device(t) as stream:`` -- the library launches on, and keeps its scratch arenas per, the CURRENT HIP
+    device; a tensor that lives on another GPU (model loaded on cuda:1 without torch.cuda.set_device) would
+    otherwise get its kernels launched on device 0 with device-1 pointers.  Makes the tensor's device current for the
+    call and hands out that device's current stream."""
+
+    def __init__(self, t):
+        dev = t.device if isinstance(t, torch.Tensor) else torch.device(t)
+        if dev.type != "cuda":
+            raise WtError("the alignment kernels only run on the GPU (got a tensor on %s)" % dev)
+        self.ctx = torch.cuda.device(dev)
+        self.dev = dev
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def device_ctx(device):
+    """torch.cuda.device(device) for a GPU device, a no-op otherwise."""
+    import contextlib
+    device = torch.device(device)
+    return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
+
+
+def pinned(t: torch.Tensor) -> torch.Tensor:
+    """Page-locked copy of a small host tensor (what an asynchronous H2D copy needs)."""
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+class HostCopy:
+    """Asynchronous device->host copy of a small tensor: queued behind the work already on the stream, read with
+    ``wait()``.  (A tensor that already lives on the host is handed back as is.)"""
+
+    def __init__(self, t: torch.Tensor):
+        self.event = None
+        if t.is_cuda:
+            self.host = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            with torch.cuda.device(t.device):
+                self.host.copy_(t, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(torch.cuda.current_stream(t.device))
+        else:
+            self.host = t
+
+    def wait(self) -> torch.Tensor:
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self.host
+
+
+def same_device(*tensors):
+    devs = {t.device for t in tensors if isinstance(t, torch.Tensor)}
+    if len(devs) > 1:
+        raise WtError(f"tensors of one call live on different devices: {sorted(map(str, devs))}")
 
 
 def _need_cuda(t: torch.Tensor, name: str):
@@ -120,27 +189,33 @@ def layout_outputs(descs: np.ndarray):
 def cost_batch(qk: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, head_idx: torch.Tensor, cost: torch.Tensor,
                medfilt_width: int = 9, qk_scale: float = 1.0):
     _need_cuda(qk, "qk")
+    same_device(qk, descs_dev, head_idx, cost)
     dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[qk.dtype]
-    rc = load().wt_cost_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
-                              head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), _stream())
+    with on_device(qk) as st:
+        rc = load().wt_cost_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
+                                  head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), st)
     _check(rc, "wt_cost_batch")
 
 
 def dtw_batch(cost: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, jumps: torch.Tensor, path_i=None, path_j=None,
               path_len=None, dist=None):
     _need_cuda(cost, "cost")
-    rc = load().wt_dtw_batch(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), len(descs), jumps.data_ptr(),
-                             _ptr(path_i), _ptr(path_j), _ptr(path_len), _ptr(dist), _stream())
+    same_device(cost, descs_dev, jumps, path_i, path_j, path_len, dist)
+    with on_device(cost) as st:
+        rc = load().wt_dtw_batch(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), len(descs), jumps.data_ptr(),
+                                 _ptr(path_i), _ptr(path_j), _ptr(path_len), _ptr(dist), st)
     _check(rc, "wt_dtw_batch")
 
 
 def align_batch(qk, descs, descs_dev, head_idx, cost, jumps, path_i=None, path_j=None, path_len=None, dist=None,
                 medfilt_width: int = 9, qk_scale: float = 1.0):
     _need_cuda(qk, "qk")
+    same_device(qk, descs_dev, head_idx, cost, jumps, path_i, path_j, path_len, dist)
     dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[qk.dtype]
-    rc = load().wt_align_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
-                               head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), jumps.data_ptr(), _ptr(path_i),
-                               _ptr(path_j), _ptr(path_len), _ptr(dist), _stream())
+    with on_device(qk) as st:
+        rc = load().wt_align_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
+                                   head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), jumps.data_ptr(), _ptr(path_i),
+                                   _ptr(path_j), _ptr(path_len), _ptr(dist), st)
     _check(rc, "wt_align_batch")
 
 
@@ -150,8 +225,9 @@ def find_start_padding(mel: torch.Tensor) -> torch.Tensor:
     mel = mel.contiguous()
     B, M, C = mel.shape
     out = torch.empty(B, dtype=torch.int32, device=mel.device)
-    _check(load().wt_find_start_padding_batch(mel.data_ptr(), B, M, C, out.data_ptr(), _stream()),
-           "wt_find_start_padding_batch")
+    with on_device(mel) as st:
+        rc = load().wt_find_start_padding_batch(mel.data_ptr(), B, M, C, out.data_ptr(), st)
+    _check(rc, "wt_find_start_padding_batch")
     return out
 
 
@@ -169,10 +245,57 @@ def logprob_gather(logits: torch.Tensor, tokens: torch.Tensor, suppress: torch.T
         suppress = suppress.to(device=logits.device).to(torch.uint8).contiguous()
         srows = 1 if suppress.dim() == 1 else suppress.shape[0]
         sp = suppress.data_ptr()
-    rc = load().wt_logprob_gather_batch(logits.data_ptr(), dt, logits.stride(0) if n > 1 else V, n, V, tokens.data_ptr(), sp,
-                                        srows, out.data_ptr(), _stream())
+    with on_device(logits) as st:
+        rc = load().wt_logprob_gather_batch(logits.data_ptr(), dt, logits.stride(0) if n > 1 else V, n, V, tokens.data_ptr(), sp,
+                                            srows, out.data_ptr(), st)
     _check(rc, "wt_logprob_gather_batch")
     return out
+
+
+def logprob_gather_rows(logits: torch.Tensor, row_index: torch.Tensor, tokens: torch.Tensor, out: torch.Tensor | None = None):
+    """out[r] = log_softmax(logits[row_index[r]])[tokens[r]].  logits: (n_rows, V) fp32/fp16 with unit column stride;
+    row_index, tokens: int32[n_out] on the GPU (rows may repeat).  No (n, V) log-prob matrix is materialised."""
+    _need_cuda(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    same_device(logits, row_index, tokens, out)
+    assert row_index.dtype == torch.int32 and tokens.dtype == torch.int32 and row_index.numel() == tokens.numel()
+    n = row_index.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=logits.device)
+    assert out.dtype == torch.float32 and out.numel() >= n and out.is_contiguous()
+    dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[logits.dtype]
+    with on_device(logits) as st:
+        rc = load().wt_logprob_gather_rows(logits.data_ptr(), dt, logits.stride(0), row_index.data_ptr(), n, logits.shape[1],
+                                           tokens.data_ptr(), out.data_ptr(), st)
+    _check(rc, "wt_logprob_gather_rows")
+    return out
+
+
+def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring: torch.Tensor, row_begin=None, row_end=None,
+                  ring_row0: int = 0):
+    """ring[b, slot, ring_row0 + r, :] = the QK logits row of query r for every selected (layer, head), every window b.
+    q_layers / k_layers: per hooked layer (B, n_q, D) / (B, n_ctx, D) projections; ring: (B, n_slots, rows, n_ctx)."""
+    import ctypes as C
+    q0, k0 = q_layers[0], k_layers[0]
+    _need_cuda(q0, "q")
+    same_device(*q_layers, *k_layers, sel_layer, sel_head, sel_slot, ring, row_begin, row_end)
+    B, n_q, D = q0.shape
+    n_ctx = k0.shape[1]
+    for q, k in zip(q_layers, k_layers):
+        assert q.shape == q0.shape and k.shape == k0.shape and q.dtype == q0.dtype == k.dtype, (q.shape, k.shape)
+        assert q.stride(2) == 1 and q.stride(1) == D and k.stride(2) == 1 and k.stride(1) == D
+        assert q.stride(0) == q0.stride(0) and k.stride(0) == k0.stride(0)
+    assert ring.dim() == 4 and ring.shape[0] == B and ring.shape[3] == n_ctx and ring[0].is_contiguous()
+    n_heads = D // 64
+    qp = (C.c_void_p * len(q_layers))(*[q.data_ptr() for q in q_layers])
+    kp = (C.c_void_p * len(k_layers))(*[k.data_ptr() for k in k_layers])
+    dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}
+    with on_device(q0) as st:
+        rc = load().wt_qk_rows_batch(qp, kp, len(q_layers), dt[q0.dtype], B, n_q, q0.stride(0), k0.stride(0), n_ctx, D,
+                                     D // n_heads, float(D // n_heads) ** -0.25, sel_layer.data_ptr(), sel_head.data_ptr(),
+                                     sel_slot.data_ptr(), sel_layer.numel(), _ptr(row_begin), _ptr(row_end), ring.data_ptr(),
+                                     dt[ring.dtype], ring.stride(0), ring.shape[2], int(ring_row0), st)
+    _check(rc, "wt_qk_rows_batch")
 
 
 def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000):
@@ -186,7 +309,8 @@ def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tenso
     mel = torch.empty((B, M, n_frames), dtype=torch.float32, device=pcm.device)
     gmax = torch.empty(B, dtype=torch.float32, device=pcm.device)
     nv = None if n_valid_samples is None else n_valid_samples.to(device=pcm.device, dtype=torch.int32).contiguous()
-    rc = load().wt_logmel_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
-                                gmax.data_ptr(), _stream())
+    with on_device(pcm) as st:
+        rc = load().wt_logmel_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
+                                    gmax.data_ptr(), st)
     _check(rc, "wt_logmel_batch")
     return mel, gmax

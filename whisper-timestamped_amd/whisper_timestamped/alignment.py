@@ -159,25 +159,95 @@ def prepare_unit(tokens, attention_weights, tokenizer, use_space=True, mfcc=None
                          refine_whisper_precision_nframes, unfinished_decoding, detect_disfluencies, tokenizer, tag)
 
 
-class AlignmentBatch:
-    """Queue AlignmentUnits, run cost + DTW for all of them with one launch
-    set, then turn jumps into words on the host."""
+class _Slot:
+    """Reusable buffers of one in-flight batch: pinned descriptor staging, device descriptors, cost matrices, and ONE
+    int32 result record (jumps | moved starts | caller's extra words) with its pinned host mirror."""
 
-    def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False):
+    def __init__(self, device):
+        self.device = device
+        self.descs_host = self.descs_dev = self.cost = self.result = self.result_host = None
+        self.event = torch.cuda.Event()
+        self.head_idx = {}
+
+    @staticmethod
+    def _grown(n):
+        return max(int(n * 1.5), 1024)
+
+    def reserve(self, desc_bytes, n_cost, n_result):
+        if self.descs_host is None or self.descs_host.numel() < desc_bytes:
+            n = self._grown(desc_bytes)
+            self.descs_host = torch.empty(n, dtype=torch.uint8).pin_memory()
+            self.descs_dev = torch.empty(n, dtype=torch.uint8, device=self.device)
+        if self.cost is None or self.cost.numel() < n_cost:
+            self.cost = torch.empty(self._grown(n_cost), dtype=torch.float32, device=self.device)
+        if self.result is None or self.result.numel() < n_result:
+            n = self._grown(n_result)
+            self.result = torch.empty(n, dtype=torch.int32, device=self.device)
+            self.result_host = torch.empty(n, dtype=torch.int32).pin_memory()
+
+    def heads(self, n_sel):
+        if n_sel not in self.head_idx:
+            self.head_idx[n_sel] = torch.arange(n_sel, dtype=torch.int32, device=self.device)
+        return self.head_idx[n_sel]
+
+
+class Workspace:
+    """Pool of _Slots of one device.  A transcription session keeps one: after the first windows nothing is allocated
+    per batch any more (descriptor staging, cost, result record and its pinned mirror are all reused), and the only
+    host<->device synchronisation of a batch is the wait on its result event in ``AlignmentBatch.collect``."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._free = []
+
+    def acquire(self):
+        return self._free.pop() if self._free else _Slot(self.device)
+
+    def release(self, slot):
+        self._free.append(slot)
+
+
+_WORKSPACES = {}
+
+
+def default_workspace(device):
+    device = torch.device(device)
+    if device not in _WORKSPACES:
+        _WORKSPACES[device] = Workspace(device)
+    return _WORKSPACES[device]
+
+
+class AlignmentBatch:
+    """Queue AlignmentUnits, run cost + DTW for all of them with one launch set, then turn jumps into words on the
+    host.  ``run()`` = ``launch()`` (asynchronous: descriptors up, kernels, nothing waits) + ``collect()`` (ONE wait on
+    the batch's result event, then host-side word assembly).  Between the two the caller may queue more GPU work
+    (the next tokens of the decoder, another batch); ``extra_words`` reserves room at the end of the result record
+    for values of its own (the batched naive strategy puts its chosen-token log-probabilities there) so that one
+    copy brings everything to the host."""
+
+    def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False, workspace=None, extra_words=0):
         self.units: list[AlignmentUnit] = []
         self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
         self.keep_cost, self.want_path = keep_cost, want_path
         self.cost = self.jumps = self.descs = None
         self.path_i = self.path_j = self.path_len = self.dist = None
+        self.workspace, self.extra_words = workspace, int(extra_words)
+        self.extra = None               # device int32 view of the caller's words (valid after launch())
+        self._slot = self._order = None
+        self._launched = self._fetched = False
 
     def add(self, unit: AlignmentUnit | None):
         if unit is not None:
+            assert not self._launched, "the batch is already in flight"
             self.units.append(unit)
         return unit
 
-    def run(self):
+    def launch(self):
+        """Asynchronous half: after this call the units' QK rows may be overwritten by later work ON THE SAME STREAM."""
+        assert not self._launched
+        self._launched = True
         if not self.units:
-            return []
+            return self
         # the library wants units grouped by F class; results are handed back in the caller's order
         order = _lib.launch_order([(u.T, u.F) for u in self.units])
         units = [self.units[i] for i in order]
@@ -185,8 +255,15 @@ class AlignmentBatch:
         dt = units[0].qk.dtype
         esz = units[0].qk.element_size()
         base = min(u.qk.data_ptr() for u in units)
-        descs = _lib.make_descs(len(units))
+        ws = self.workspace or default_workspace(dev)
+        assert ws.device == dev, f"workspace of {ws.device} used for units on {dev}"
+        slot = ws.acquire()
+        n_units = len(units)
         n_sel = units[0].qk.shape[0]
+        desc_bytes = n_units * _lib.SEG_DTYPE.itemsize
+        slot.reserve(desc_bytes, 0, 0)
+        descs = slot.descs_host.numpy()[:desc_bytes].view(_lib.SEG_DTYPE)      # written in place in pinned memory
+        descs[:] = 0
         for d, u in zip(descs, units):
             assert u.qk.dtype == dt and u.qk.device == dev and u.qk.shape[0] == n_sel and u.qk.stride(2) == 1
             off = u.qk.data_ptr() - base
@@ -197,52 +274,88 @@ class AlignmentBatch:
             d["T"], d["F"] = u.T, u.F
             d["start_token"], d["pad_from"] = u.start_token, u.pad_from
         n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
-        descs_dev = _lib.descs_to_device(descs, dev)
-        head_idx = torch.arange(n_sel, dtype=torch.int32, device=dev)
-        cost = torch.empty(n_cost, dtype=torch.float32, device=dev)
-        jumps = torch.empty(n_jumps, dtype=torch.int32, device=dev)
-        if self.want_path:
-            self.path_i = torch.empty(n_path, dtype=torch.int32, device=dev)
-            self.path_j = torch.empty(n_path, dtype=torch.int32, device=dev)
-            self.path_len = torch.empty(len(units), dtype=torch.int32, device=dev)
-            self.dist = torch.empty(len(units), dtype=torch.float64, device=dev)
-        # a fake base tensor is not needed: the ABI takes raw pointers
-        L = _lib.load()
-        rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
-                              len(units), head_idx.data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
-                              cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
-                              _lib._ptr(self.path_len), _lib._ptr(self.dist), _lib._stream())
-        _lib._check(rc, "wt_align_batch")
-        self.descs, self.cost, self.jumps = descs, cost, jumps
-        both = jumps
-        if any(u.detect_disfluencies for u in units):          # token starts moved to their last attention peak
-            both = torch.empty(2 * n_jumps, dtype=torch.int32, device=dev)
-            both[:n_jumps].copy_(jumps)
-            rc = L.wt_disfluency_batch(cost.data_ptr(), descs_dev.data_ptr(), len(units), jumps.data_ptr(),
-                                       both[n_jumps:].data_ptr(), DISFLUENCY_MIN_PROMINENCE, DISFLUENCY_MIN_WIDTH,
-                                       _lib._stream())
-            _lib._check(rc, "wt_disfluency_batch")
-        both_host = both.cpu().numpy()                         # the one device->host sync of the batch (KBs)
-        jumps_host = both_host[:n_jumps]
-        starts_host = both_host[n_jumps:] if both is not jumps else None
+        disfl = any(u.detect_disfluencies for u in units)
+        n_result = n_jumps * (2 if disfl else 1) + self.extra_words
+        slot.reserve(desc_bytes, n_cost, n_result)
+        descs = slot.descs_host.numpy()[:desc_bytes].view(_lib.SEG_DTYPE)      # (reserve never reallocates the staging)
+        with _lib.on_device(dev) as stream:
+            descs_dev = slot.descs_dev[:desc_bytes]
+            descs_dev.copy_(slot.descs_host[:desc_bytes], non_blocking=True)
+            cost = slot.cost[:n_cost]
+            jumps = slot.result[:n_jumps]
+            if self.want_path:
+                self.path_i = torch.empty(n_path, dtype=torch.int32, device=dev)
+                self.path_j = torch.empty(n_path, dtype=torch.int32, device=dev)
+                self.path_len = torch.empty(n_units, dtype=torch.int32, device=dev)
+                self.dist = torch.empty(n_units, dtype=torch.float64, device=dev)
+            L = _lib.load()
+            rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
+                                  n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
+                                  cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
+                                  _lib._ptr(self.path_len), _lib._ptr(self.dist), stream)
+            _lib._check(rc, "wt_align_batch")
+            if disfl:                                          # token starts moved to their last attention peak
+                rc = L.wt_disfluency_batch(cost.data_ptr(), descs_dev.data_ptr(), n_units, jumps.data_ptr(),
+                                           slot.result[n_jumps:2 * n_jumps].data_ptr(), DISFLUENCY_MIN_PROMINENCE,
+                                           DISFLUENCY_MIN_WIDTH, stream)
+                _lib._check(rc, "wt_disfluency_batch")
+        self._slot, self._order, self._sorted_units = slot, order, units
+        self._n_jumps, self._disfl, self._n_result = n_jumps, disfl, n_result
+        self.descs, self.cost, self.jumps = descs.copy(), cost, jumps
+        self.extra = slot.result[n_result - self.extra_words:n_result] if self.extra_words else None
+        return self
+
+    def fetch(self):
+        """Queue the ONE device->host copy of the result record (KBs) behind whatever has been launched so far."""
+        if not self._launched:
+            self.launch()
+        if self._fetched or not self.units:
+            return self
+        self._fetched = True
+        slot = self._slot
+        with torch.cuda.device(slot.device):
+            slot.result_host[:self._n_result].copy_(slot.result[:self._n_result], non_blocking=True)
+            slot.event.record(torch.cuda.current_stream(slot.device))
+        return self
+
+    def collect(self):
+        """Wait for the record (the one synchronisation of the batch) and assemble the words, caller's order."""
+        if not self.units:
+            return []
+        self.fetch()
+        slot, units, order = self._slot, self._sorted_units, self._order
+        slot.event.synchronize()
+        host = slot.result_host[:self._n_result].numpy().copy()
+        n_jumps = self._n_jumps
+        jumps_host = host[:n_jumps]
+        starts_host = host[n_jumps:2 * n_jumps] if self._disfl else None
+        self.extra_host = host[self._n_result - self.extra_words:] if self.extra_words else None
         out = [None] * len(units)
-        self._slot = [0] * len(units)                # caller's unit index -> descriptor index
-        for k, (d, u) in enumerate(zip(descs, units)):
+        self._slot_of = [0] * len(units)             # caller's unit index -> descriptor index
+        for k, (d, u) in enumerate(zip(self.descs, units)):
             j0 = int(d["jumps_offset"])
             jm = jumps_host[j0:j0 + u.T + 1].astype(np.int64)
             js = starts_host[j0:j0 + u.T + 1].astype(np.int64) if starts_host is not None else None
             out[order[k]] = finish_unit(u, jm, js)
-            self._slot[order[k]] = k
+            self._slot_of[order[k]] = k
+        if not self.keep_cost:                       # the cost matrices live in the slot: hand it back unless asked to keep
+            (self.workspace or default_workspace(slot.device)).release(slot)
+            self._slot = None
+            self.cost = self.jumps = self.extra = None
         return out
 
+    def run(self):
+        return self.launch().collect()
+
     def unit_cost(self, k):
-        k = self._slot[k]
+        assert self.keep_cost, "AlignmentBatch(keep_cost=True) keeps the cost matrices after collect()"
+        k = self._slot_of[k]
         d = self.descs[k]
         c0 = int(d["cost_offset"])
         return self.cost[c0:c0 + int(d["T"]) * int(d["F"])].reshape(int(d["T"]), int(d["F"]))
 
     def unit_path(self, k):
-        k = self._slot[k]
+        k = self._slot_of[k]
         d = self.descs[k]
         n = int(self.path_len[k])
         p0 = int(d["path_offset"])
@@ -266,6 +379,15 @@ def detect_disfluences(unit: AlignmentUnit, jumps, jumps_start):
         else:
             disfluences[i_token + 1] = (begin, end)
     return jumps_start, disfluences
+
+
+def planned_words(unit: AlignmentUnit):
+    """(pieces, ids) of the words ``finish_unit`` will return for this unit, in order, known BEFORE the kernels run:
+    which words exist is decided by the token split alone (words.words_from_jumps drops the timestamp words and
+    "<|...|>" texts; a disfluency mark "[*]" may be inserted later but carries no tokens)."""
+    keep = slice(1, None) if unit.unfinished_decoding else slice(1, -1)
+    return [(pieces, ids) for text, pieces, ids in zip(unit.words[keep], unit.word_pieces[keep], unit.word_ids[keep])
+            if not text.startswith("<|")]
 
 
 def finish_unit(unit: AlignmentUnit, jumps, jumps_start=None):

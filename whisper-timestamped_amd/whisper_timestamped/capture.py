@@ -64,9 +64,11 @@ class QKCaptureRing:
         if heads.numel() == 0:
             return
         dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[qk.dtype]
-        rc = self._lib.wt_capture_rows(qk.data_ptr(), dt, qk.shape[1], qk.shape[2], self.n_ctx, heads.data_ptr(),
-                                       self._slots[layer_index].data_ptr(), heads.numel(), self.buf.data_ptr(), self._dt,
-                                       self.capacity, int(row), _lib._stream())
+        _lib.same_device(qk, self.buf)
+        with _lib.on_device(self.buf) as st:
+            rc = self._lib.wt_capture_rows(qk.data_ptr(), dt, qk.shape[1], qk.shape[2], self.n_ctx, heads.data_ptr(),
+                                           self._slots[layer_index].data_ptr(), heads.numel(), self.buf.data_ptr(), self._dt,
+                                           self.capacity, int(row), st)
         _lib._check(rc, "wt_capture_rows")
 
     def write_from_projections(self, layer_index: int, q: torch.Tensor, k: torch.Tensor, row0: int, n_rows: int = 1):
@@ -88,9 +90,11 @@ class QKCaptureRing:
         if not kr.is_contiguous():
             kr = kr.contiguous()
         dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[q.dtype]
-        rc = self._lib.wt_qk_rows(qr.data_ptr(), kr.data_ptr(), dt, n_rows, self.n_ctx, d_model, head_dim,
-                                  float(head_dim) ** -0.25, heads.data_ptr(), self._slots[layer_index].data_ptr(),
-                                  heads.numel(), self.buf.data_ptr(), self._dt, self.capacity, int(row0), _lib._stream())
+        _lib.same_device(q, k, self.buf)
+        with _lib.on_device(self.buf) as st:
+            rc = self._lib.wt_qk_rows(qr.data_ptr(), kr.data_ptr(), dt, n_rows, self.n_ctx, d_model, head_dim,
+                                      float(head_dim) ** -0.25, heads.data_ptr(), self._slots[layer_index].data_ptr(),
+                                      heads.numel(), self.buf.data_ptr(), self._dt, self.capacity, int(row0), st)
         _lib._check(rc, "wt_qk_rows")
 
     def rows(self, rows) -> torch.Tensor:

@@ -27,6 +27,10 @@ from .words import (AUDIO_SAMPLES_PER_TOKEN, AUDIO_TIME_PER_TOKEN, HOP_LENGTH, N
 
 logger = logging.getLogger("whisper_timestamped")
 
+# trust_whisper_timestamps=False: how many of whisper's (independent) 30 s windows share one launch set in the second
+# pass (batched.py).  0 = the reference's shape, one window at a time.
+BATCH_WINDOWS = 32
+
 
 def get_audio_tensor(audio, device="cpu"):
     """transcribe.py:1340-1347"""
@@ -153,6 +157,55 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
         words = []
         previous_end = 0
         segments = transcription["segments"]
+        audio_dev = None
+        pending = []                       # trust_whisper_timestamps=False: independent windows, aligned as one batch
+
+        def finish_window(ws, word_logprobs, tokens, start, i_segment, segment, token_to_segment, check, last_token_check):
+            """What the reference does with a window's words (:1264-1323).  word_logprobs: per word, the CPU fp32
+            log-probabilities of its kept tokens (None when confidences are off)."""
+            nonlocal previous_end
+            segment_logprobs = []
+            i_token = 1
+            for k, word in enumerate(ws):
+                word["start"] = round(word["start"] + start, 2)
+                word["end"] = round(word["end"] + start, 2)
+                if trust_whisper_timestamps:
+                    word.update({"idx_segment": i_segment})
+                else:
+                    assert i_token < len(tokens)
+                    assert not len(word["tokens_indices"]) or word["tokens_indices"][0] == tokens[i_token]
+                    word.update({"idx_segment": token_to_segment[i_token]})
+                    i_token += len(word["tokens"])
+                    while i_token < len(tokens) and tokens[i_token] >= tokenizer.timestamp_begin:
+                        i_token += 1
+                check.extend(word["tokens_indices"])
+                if compute_word_confidence:
+                    wl = word_logprobs[k]
+                    if len(wl):
+                        segment_logprobs.append(wl)
+                        conf = wl.mean().exp().item()
+                    else:
+                        conf = 0
+                    word.update({"confidence": round_confidence(conf)})
+                words.append(word)
+                if verbose:
+                    from .transcribe import print_timestamped
+                    print_timestamped(word)
+            if last_token_check is not None:
+                check.append(last_token_check)
+            if trust_whisper_timestamps:
+                if check != segment["tokens"]:
+                    assert len(check) < len(segment["tokens"]), \
+                        f"First should be longer by one token: '{tokenizer.decode_with_timestamps(check)}' should include '{tokenizer.decode_with_timestamps(segment['tokens'])}'"
+                    assert check[:-1] == segment["tokens"][:len(check) - 1], \
+                        f"Got inconsistent tokens: {tokenizer.decode_with_timestamps(check)} != {tokenizer.decode_with_timestamps(segment['tokens'])}"
+                    segment["tokens"] = check
+                    segment["text"] = tokenizer.decode(segment["tokens"])
+            if len(segment_logprobs):
+                segment.update({"confidence": round_confidence(torch.cat(segment_logprobs).mean().exp().item())})
+            if len(ws):
+                previous_end = ws[-1]["end"]
+
         for i_segment, segment in enumerate(segments):
             start = end = tokens = None
             if trust_whisper_timestamps:
@@ -205,6 +258,19 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
 
             start_sample = min(round(start * SAMPLE_RATE), audio.shape[-1])
             end_sample = min(round(end * SAMPLE_RATE), audio.shape[-1])
+
+            if not trust_whisper_timestamps and BATCH_WINDOWS:
+                # whisper's 30 s seek groups do not depend on each other (:1197-1202): queue the window, all of them go
+                # through mel / encoder / decoder / alignment / confidence gather together (batched.py)
+                if audio_dev is None:
+                    audio_dev = audio.to(dev).float()                # the recording crosses PCIe once
+                from .batched import WindowJob
+                pending.append(WindowJob(audio_minimum_padding(audio_dev[start_sample:end_sample]), tokens,
+                                         end_sample - start_sample,
+                                         tag=(start, i_segment, segment, token_to_segment)))
+                window_tokens, token_to_segment = [], []
+                continue
+
             sub_audio = audio_minimum_padding(audio[start_sample:end_sample])
             # log-mel of the crop on the GPU, zero padded / cut to 3000 frames (log_mel_spectrogram + pad_or_trim, :1213-1215)
             n_valid = sub_audio.shape[-1]
@@ -272,54 +338,37 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
                     steps.extend(range(i_tok, i_tok + len(ids)))
                     toks.extend(ids)
                 i_tok = i_end
-            lp = None
-            if steps:
-                rows = logits[torch.tensor(steps, device=dev)] if steps != list(range(steps[0], steps[0] + len(steps))) \
-                    else logits[steps[0]:steps[0] + len(steps)]
-                lp = _lib.logprob_gather(rows.float().contiguous(), torch.tensor(toks, dtype=torch.int32)).cpu()
+            word_logprobs = None
+            if compute_word_confidence:
+                lp = torch.empty(0)
+                if steps:
+                    rows = logits[torch.tensor(steps, device=dev)] if steps != list(range(steps[0], steps[0] + len(steps))) \
+                        else logits[steps[0]:steps[0] + len(steps)]
+                    lp = _lib.logprob_gather(rows.float().contiguous(), torch.tensor(toks, dtype=torch.int32)).cpu()
+                word_logprobs = [lp[off:off + n] for off, n in plan]
 
-            segment_logprobs = []
-            i_token = 1
-            for k, word in enumerate(ws):
-                word["start"] = round(word["start"] + start, 2)
-                word["end"] = round(word["end"] + start, 2)
-                if trust_whisper_timestamps:
-                    word.update({"idx_segment": i_segment})
-                else:
-                    assert i_token < len(tokens)
-                    assert not len(word["tokens_indices"]) or word["tokens_indices"][0] == tokens[i_token]
-                    word.update({"idx_segment": token_to_segment[i_token]})
-                    i_token += len(word["tokens"])
-                    while i_token < len(tokens) and tokens[i_token] >= tokenizer.timestamp_begin:
-                        i_token += 1
-                check.extend(word["tokens_indices"])
-                if compute_word_confidence:
-                    off, n = plan[k]
-                    if n:
-                        wl = lp[off:off + n]
-                        segment_logprobs.append(wl)
-                        conf = wl.mean().exp().item()
-                    else:
-                        conf = 0
-                    word.update({"confidence": round_confidence(conf)})
-                words.append(word)
-
-            if last_token_check is not None:
-                check.append(last_token_check)
-            if trust_whisper_timestamps:
-                if check != segment["tokens"]:
-                    assert len(check) < len(segment["tokens"]), \
-                        f"First should be longer by one token: '{tokenizer.decode_with_timestamps(check)}' should include '{tokenizer.decode_with_timestamps(segment['tokens'])}'"
-                    assert check[:-1] == segment["tokens"][:len(check) - 1], \
-                        f"Got inconsistent tokens: {tokenizer.decode_with_timestamps(check)} != {tokenizer.decode_with_timestamps(segment['tokens'])}"
-                    segment["tokens"] = check
-                    segment["text"] = tokenizer.decode(segment["tokens"])
-            if len(segment_logprobs):
-                segment.update({"confidence": round_confidence(torch.cat(segment_logprobs).mean().exp().item())})
-            if len(ws):
-                previous_end = ws[-1]["end"]
+            finish_window(ws, word_logprobs, tokens, start, i_segment, segment, token_to_segment, check, last_token_check)
             if not trust_whisper_timestamps:
                 window_tokens, token_to_segment = [], []
+
+        if pending:
+            from .batched import BatchedAligner, align_windows
+            for h in hooks:                # the aligner installs its own (batched) capture hooks
+                h.remove()
+            hooks = []
+            aligner = BatchedAligner(model, tokenizer, language=language, use_space=use_space,
+                                     alignment_heads=alignment_heads,
+                                     word_alignment_most_top_layers=word_alignment_most_top_layers,
+                                     refine_whisper_precision_nframes=refine_whisper_precision_nframes,
+                                     remove_punctuation_from_words=remove_punctuation_from_words,
+                                     compute_word_confidence=compute_word_confidence,
+                                     include_punctuation_in_confidence=include_punctuation_in_confidence,
+                                     detect_disfluencies=detect_disfluencies, fused_attention=FUSED_ATTENTION)
+            for res in align_windows(aligner, pending, BATCH_WINDOWS):
+                start, i_segment, segment, t2s = res.tag
+                check = [] if res.first_token_check is None else [res.first_token_check]
+                finish_window(res.words, res.word_logprobs, res.tokens, start, i_segment, segment, t2s, check,
+                              res.last_token_check)
     finally:
         for h in hooks:
             h.remove()
