@@ -15,6 +15,18 @@ For N>1 every rank owns its own 32 chunks (units are independent: weak
 scaling, no data-path collective); the per-step result records are gathered
 to rank 0 over RCCL, which is where the reference assembles words.
 
+Timing: the region of EXACTLY --steps steps (barrier + synchronize on both sides,
+max over ranks) is repeated until at least --min-seconds of GPU work have been
+timed (never fewer than 5 regions); ms_per_step / value are the MEDIAN region,
+min and max are reported next to it.
+
+The same line carries the transcribe()-level number ("e2e"): 32 synthetic 30 s
+chunks per sub-batch through log-mel -> whisper-base encoder -> teacher-forced
+decoder (fixed synthetic transcript) -> wt_qk_rows_batch -> ONE wt_align_batch
+-> ONE wt_logprob_gather_rows -> words (whisper_timestamped/batched.py), with
+the share of the alignment kernels in the GPU time and the same chunks through
+the reference-shaped CPU path (oracle/, same model on the CPU) beside it.
+
 Prints ONE JSON line (rank 0).  metric = audio-seconds aligned per second.
 """
 import argparse
@@ -154,23 +166,25 @@ STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel
                  "dtw": ["dtw_kernel"], "logprob": ["logprob_gather_kernel"]}
 
 
-def committed_traffic(stage):
-    """HBM bytes per launch of a stage's kernels from the newest committed PMC summary (profiles/*traffic.json:
-    rocprofv3 FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes of this same bench command).
-    PMC counters cannot be read from inside the timed run, so this is the committed measurement, or None."""
+def committed_traffic(stage, workload):
+    """HBM bytes per launch of a stage's kernels from the newest committed PMC summary OF THIS WORKLOAD
+    (profiles/*traffic*.json written by tools/pmc_traffic.py --workload: rocprofv3 FETCH_SIZE x2 [gfx950 correction] +
+    WRITE_SIZE, separate passes of this same bench command).  PMC counters cannot be read from inside the timed run,
+    so this is the committed measurement -- or None when no summary of the same workload exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
-    if not files:
-        return None, None
-    try:
-        data = json.load(open(files[-1]))
-    except Exception:
-        return None, None
-    tot = 0
-    for kname, v in data.items():
-        if any(k in kname for k in STAGE_KERNELS[stage]):
-            tot += int(v.get("hbm_bytes", 0))
-    return (tot or None), os.path.basename(files[-1])
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            continue
+        if data.get("_workload") != workload:
+            continue
+        tot = 0
+        for kname, v in data.items():
+            if isinstance(v, dict) and any(k in kname for k in STAGE_KERNELS[stage]):
+                tot += int(v.get("hbm_bytes", 0))
+        return (tot or None), os.path.basename(path)
+    return None, None
 
 
 def _stage_calls(w):
@@ -314,39 +328,201 @@ def algorithmic_bytes(cfg):
     rows = sum(t for t, _ in units)
     return {
         "logmel": n * (480000 * 4 + M * 3000 * 4),
-        "padding": n * M * 3000 * 4,
+        "padding": n * M * 4,                               # an unpadded window is decided by its last column
         "cost": A * tf * s_in + tf * 4,                    # selected-head logits once, cost once
         "dtw": tf * 4 + 4 * (rows + len(units)),           # read cost once, write jumps
         "logprob": rows * (V * 4 + 8),                     # read each logit row once
     }
 
 
-def cpu_baseline(cfg, w, budget_s=20.0):
-    """The oracle (CPU restatement of the reference path) on a bounded sample
-    of the same workload, host cores of this box, rank 0 only."""
+def cpu_baseline(cfg, w, budget_s=12.0, threads=None, distinct=32):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload, host cores of this
+    box, rank 0 only.  The sample cycles over `distinct` DIFFERENT chunks (no cache-warm repeats of a few inputs).
+    threads=1: the reference's alignment is effectively single-threaded (scipy / dtw-python do not thread)."""
     from oracle import align_ref as O
-    qk = w["qk"][:4].float().cpu()
-    logits = w["logits"][: 4 * cfg["T"]].cpu()
-    tokens = w["tokens"][: 4 * cfg["T"]].cpu().numpy()
-    pcm = w["pcm"][:4].cpu()
-    done, t0 = 0, time.perf_counter()
-    while True:
-        b = done % 4
-        mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b], cfg["n_mels"]), 3000)
-        O.find_start_padding_ref(mel[None])
-        cost = O.cost_matrix_ref(qk[b][:, :, :cfg["F"]], 9, 1.0, None, 0)
-        r = O.dtw_ref(cost)
-        O.jumps_from_path(r.index1s, r.index2s)
-        O.token_logprob_gather_ref(logits[b * cfg["T"]:(b + 1) * cfg["T"]], tokens[b * cfg["T"]:(b + 1) * cfg["T"]])
-        done += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= 64:
-            break
-    return {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s", "cores": int(torch.get_num_threads()),
+    T = cfg["T"]
+    nd = min(distinct, cfg["n_chunks"])
+    qk = w["qk"][:nd].float().cpu()
+    logits = w["logits"][: nd * T].cpu()
+    tokens = w["tokens"][: nd * T].cpu().numpy()
+    pcm = w["pcm"][:nd].cpu()
+    before = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    try:
+        done, t0 = 0, time.perf_counter()
+        while True:
+            b = done % nd
+            mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b], cfg["n_mels"]), 3000)
+            O.find_start_padding_ref(mel[None])
+            cost = O.cost_matrix_ref(qk[b][:, :, :cfg["F"]], 9, 1.0, None, 0)
+            r = O.dtw_ref(cost)
+            O.jumps_from_path(r.index1s, r.index2s)
+            O.token_logprob_gather_ref(logits[b * T:(b + 1) * T], tokens[b * T:(b + 1) * T])
+            done += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or done >= 2 * nd:
+                break
+        used = int(torch.get_num_threads())
+    finally:
+        torch.set_num_threads(before)
+    return {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s", "cores": used,
             "kind": "port",
-            "sample": f"{done} of the same 30 s K-full chunks through oracle/ (scipy median_filter + torch CPU softmax/"
-                      f"mean/norm/log_softmax/stft with {torch.get_num_threads()} intra-op threads, single-thread C "
-                      f"DTW + backtrack), {el:.1f} s wall"}
+            "sample": f"{done} 30 s K-full chunks ({min(done, nd)} distinct) through oracle/ (scipy median_filter + torch CPU "
+                      f"softmax/mean/norm/log_softmax/stft with {used} intra-op thread(s), single-thread C DTW + backtrack), "
+                      f"{el:.1f} s wall"}
+
+
+# --------------------------------------------------------------------------------------------------- transcribe() level
+E2E_SEGMENTS = [(0, 280), (300, 560), (580, 900), (920, 1200), (1220, 1480)]    # 5 timestamped segments per window
+E2E_TEXT_PER_SEGMENT = 17                                                       # ~86 text tokens per window (SURVEY 8d set M)
+
+
+def e2e_transcript(tokenizer, seed):
+    """The fixed synthetic transcript of one 30 s window, as whisper hands a window's tokens to the naive strategy with
+    trust_whisper_timestamps=False: <|s|> text <|e|><|s'|> text <|e'|> ..."""
+    rs = np.random.RandomState(seed)
+    ts0 = tokenizer.timestamp_begin
+    banned = set(getattr(tokenizer, "non_speech_tokens", ())) | {220}
+    toks = []
+    for s, e in E2E_SEGMENTS:
+        text = [int(t) for t in rs.randint(300, 40000, size=E2E_TEXT_PER_SEGMENT)]
+        toks += [ts0 + s] + [t if t not in banned else 300 for t in text] + [ts0 + e]
+    return toks
+
+
+def e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm, window_tokens):
+    """One window the way the reference's naive loop does it (transcribe.py:1204-1300), on the CPU through oracle/:
+    torch.stft log-mel, the model unfused with every hooked layer's QK observed, log_softmax of the whole (T, V)
+    block, the oracle's perform_word_alignment, a Python loop of logprobs[:, step, tok] reads."""
+    from oracle import align_ref as O
+    import torch.nn.functional as F
+    ts0 = tokenizer.timestamp_begin
+    mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm, model_cpu.dims.n_mels), 3000).unsqueeze(0)
+    toks = list(window_tokens)
+    while toks[0] >= ts0:
+        toks = toks[1:]
+    while toks[-1] >= ts0:
+        toks = toks[:-1]
+    sot = tokenizer.sot_sequence
+    if len(sot) == 3:
+        sot = (sot[0], tokenizer.to_language_token("en"), sot[2])
+    toks = [*sot, ts0] + toks
+    i_start = len(sot)
+    att = [None] * len(model_cpu.decoder.blocks)
+    hooks = [blk.cross_attn.register_forward_hook(lambda m, i, o, k=k: att.__setitem__(k, o[-1]))
+             for k, blk in enumerate(model_cpu.decoder.blocks)]
+    try:
+        with torch.no_grad(), W.model.disable_sdpa():
+            logprobs = F.log_softmax(model_cpu(mel, torch.tensor(toks, dtype=torch.int32).unsqueeze(0)), dim=-1)
+    finally:
+        for h in hooks:
+            h.remove()
+    end_token = ts0 + round(min(480000, pcm.shape[-1]) // 320)
+    toks = toks[i_start:] + [end_token]
+    att = [w[:, :, i_start - 1:, :] for w in att]
+    ws = O.perform_word_alignment_ref(toks, att, tokenizer, use_space=True, alignment_heads=np.asarray(heads), mfcc=mel,
+                                      refine_whisper_precision_nframes=25, detect_disfluencies=False)
+    for word in ws:
+        ids = word["tokens_indices"]
+        lp = [logprobs[:, step, tok] for step, tok in zip(range(i_start, i_start + len(ids)), ids)]
+        i_start += len(word["tokens"])
+        word["confidence_raw"] = torch.cat(lp).mean().exp().item() if lp else 0.0
+    return ws
+
+
+def run_e2e(dev, args, rank, world, dist):
+    """audio-seconds transcribed-with-word-timestamps per second at the transcribe() level (SURVEY 8d "End-to-end
+    audio-s/s"): whisper-base, 32 synthetic 30 s chunks per launch set, teacher-forced transcript."""
+    import whisper_double as W          # tests/whisper_double: stand-in for openai-whisper (absent from this image)
+    W.install()
+    from whisper_timestamped.alignment import head_pairs
+    from whisper_timestamped.batched import BatchedAligner, WindowJob, align_windows
+    from whisper_timestamped.transcribe import get_alignment_heads
+    n_per, steps = 32, args.e2e_steps
+    model = W.build_model("base", seed=0, device=dev)
+    if hasattr(model, "alignment_heads"):
+        del model.alignment_heads                          # -> the published whisper-base heads (parameter-count table)
+    heads = head_pairs(get_alignment_heads(model))
+    tokenizer = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    pcm = torch.randn((n_per, 480000), generator=g, device=dev) * 0.1
+    transcripts = [e2e_transcript(tokenizer, 100 + k) for k in range(n_per)]
+    jobs = [WindowJob(pcm[k % n_per], transcripts[k % n_per], 480000, tag=k) for k in range(n_per * steps)]
+    out = {"workload": f"whisper-base (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
+                       f"{len(transcripts[0])} window tokens in {len(E2E_SEGMENTS)} timestamped segments, teacher forced "
+                       f"(naive strategy, trust_whisper_timestamps=False shape)", "chunks_per_launch": n_per,
+           "launch_sets": steps, "alignment_heads": len(heads)}
+
+    def timed(aligner, label):
+        list(align_windows(aligner, jobs[:n_per], n_per))                    # warm-up (allocations, GEMM plans)
+        torch.cuda.synchronize()
+        aligner.timeline = []
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        res = list(align_windows(aligner, jobs, n_per))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        tl = aligner.timeline
+        aligner.timeline = None
+        stage = {k: float(np.mean([t[k] for t in tl])) for k in tl[0]} if tl else {}
+        gpu_ms = sum(stage.values())
+        align_ms = sum(v for k, v in stage.items() if k != "model")
+        n_words = sum(len(r.words) for r in res)
+        assert all(len(r.words) > 0 for r in res) and n_words > 0
+        return res, {"audio_s_per_s": round(world * 30.0 * len(jobs) / el, 1), "ms_per_launch_set": round(el / steps * 1e3, 3),
+                     "gpu_ms_per_launch_set": round(gpu_ms, 3),
+                     "gpu_stage_ms": {k: round(v, 3) for k, v in stage.items()},
+                     "alignment_share_of_gpu_time": round(align_ms / gpu_ms, 4) if gpu_ms else None,
+                     "host_bound_fraction": round(max(0.0, 1.0 - gpu_ms * steps / (el * 1e3)), 4),
+                     "words_per_launch_set": n_words // steps}
+
+    opts = dict(language="en", alignment_heads=torch.tensor(heads), refine_whisper_precision_nframes=25)
+    aligner = BatchedAligner(model, tokenizer, **opts)
+    res32, fp32 = timed(aligner, "fp32")
+    out.update(fp32)
+    out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
+    # the reference's GPU default is fp16=True: same pipeline with the model and its input in half precision
+    model16 = W.build_model("base", seed=0, device=dev).half()
+    if hasattr(model16, "alignment_heads"):
+        del model16.alignment_heads
+    _, fp16 = timed(BatchedAligner(model16, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
+    out["fp16_model"] = fp16
+    del model16
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the same chunks through the reference-shaped CPU path, bounded sample
+        model_cpu = W.build_model("base", seed=0, device="cpu")
+        pcm_cpu = pcm[:8].cpu()
+        done, worst_t, worst_c, t0 = 0, 0.0, 0.0, time.perf_counter()
+        while done < 8:
+            ws = e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm_cpu[done], transcripts[done])
+            got = res32[done]
+            assert [x["text"] for x in got.words] == [x["text"] for x in ws], "GPU and CPU words differ"
+            for a, lp, b in zip(got.words, got.word_logprobs, ws):
+                worst_t = max(worst_t, abs(a["start"] - b["start"]), abs(a["end"] - b["end"]))
+                conf = lp.mean().exp().item() if len(lp) else 0.0
+                worst_c = max(worst_c, abs(conf - b["confidence_raw"]))
+            done += 1
+            if time.perf_counter() - t0 > args.e2e_cpu_budget:
+                break
+        el = time.perf_counter() - t0
+        out["cpu_baseline_e2e"] = {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s",
+                                   "cores": int(torch.get_num_threads()), "kind": "port",
+                                   "sample": f"{done} of the same chunks, one at a time as the reference does: torch.stft log-mel, "
+                                             f"the same whisper-base on the CPU with unfused attention and per-layer QK capture, "
+                                             f"log_softmax of the (T, V) block, oracle perform_word_alignment, {el:.1f} s wall"}
+        out["parity_vs_cpu_reference_path"] = {"chunks": done, "max_abs_dt_word_s": round(worst_t, 4),
+                                               "max_abs_dconfidence_before_rounding": float(f"{worst_c:.3g}")}
+        out["speedup_vs_cpu_e2e"] = round(out["audio_s_per_s"] / out["cpu_baseline_e2e"]["value"], 1)
+    return out
 
 
 def main():
@@ -355,7 +531,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the --steps region is repeated until this much time has been measured (>= 5 regions)")
+    ap.add_argument("--repeats", type=int, default=0, help="fixed number of timed regions (0 = from --min-seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", default="auto", choices=["auto", "on", "off"],
+                    help="transcribe()-level leg (whisper-base, batched.py); auto = with the default workload")
+    ap.add_argument("--e2e-steps", type=int, default=6, help="launch sets of 32 chunks in the e2e timed region")
+    ap.add_argument("--e2e-cpu-budget", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph (fixed shapes); stage times then come from an eager "
                          "pass BEFORE the timed region (events cannot be read back from inside a graph)")
@@ -435,30 +618,46 @@ def main():
         return {st: (marks[i], marks[i + 1]) for i, st in enumerate(order)}
 
     evs = [make_events() for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if graph is not None:
-        for k in range(args.steps):                  # eager pass for the per-stage breakdown (NOT timed below)
-            full_step(evs[k])
+    stage_samples = {s: [] for s in STAGES}
+
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks; seconds."""
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(args.steps):
-            graph.replay()
-    else:
+        if graph is not None:
+            for k in range(args.steps):
+                graph.replay()
+        else:
+            for k in range(args.steps):
+                full_step(evs[k])
+        if gather_buf is not None:
+            gather_buf.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        if graph is None:
+            for s in STAGES:
+                stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
+        return el
+
+    if graph is not None:                            # eager pass for the per-stage breakdown (NOT part of the timing)
         for k in range(args.steps):
             full_step(evs[k])
-    if gather_buf is not None:
-        gather_buf.drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        torch.cuda.synchronize()
+        for s in STAGES:
+            stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
+    regions = [timed_region()]
+    n_regions = args.repeats or int(min(2000, max(5, np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
+    while len(regions) < n_regions:                  # (every rank derives the same count from the max-reduced first region)
+        regions.append(timed_region())
+    elapsed = float(np.median(regions))
 
     # sanity inside the bench: the ridge is recovered and log-probs are finite
     torch.cuda.synchronize()
@@ -472,9 +671,20 @@ def main():
     assert np.median(np.concatenate(devs)) <= 3
     assert np.isfinite(w["host_logprob"].numpy()).all()
 
+    cpu_lines = {}
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and not cfg.get("units"):   # rank 0 at N=1 only (fixed-shape workloads)
+        cpu_lines["cpu_baseline"] = cpu_baseline(cfg, w)
+        cpu_lines["cpu_baseline_1thread"] = cpu_baseline(cfg, w, budget_s=8.0, threads=1)
+
+    e2e = None
+    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
+        for k in ("qk", "logits", "cost", "mel"):      # the kernel-level inputs are not needed any more
+            w[k] = None
+        torch.cuda.empty_cache()
+        e2e = run_e2e(dev, args, rank, world, dist)
+
     if rank == 0:
-        stage_ms = {s: float(np.mean([evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps)]))
-                    for s in STAGES}
+        stage_ms = {s: float(np.median(stage_samples[s])) for s in STAGES}
         ab = algorithmic_bytes(cfg)
         dom = max(stage_ms, key=stage_ms.get)
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
@@ -482,7 +692,7 @@ def main():
                       "GBps": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1),
                       "frac_hbm": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for s in STAGES}
         ms_per_step = elapsed / args.steps * 1e3
-        traffic, traffic_src = committed_traffic(dom)
+        traffic, traffic_src = committed_traffic(dom, args.workload)
         out = {
             "metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks",
             "value": round(world * n * 30.0 * args.steps / elapsed, 1),
@@ -495,14 +705,19 @@ def main():
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph),
                        "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
+            "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region",
+                       "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+                       "timed_seconds_total": round(float(sum(regions)), 3)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],
                          "achievable_copy_GBps_guide": 6290.0, "achievable_read_GBps_probe": 6600.0},
             "stages": stages,
         }
-        if not args.no_cpu_baseline and world == 1 and not cfg.get("units"):      # rank 0 at N=1 only (fixed-shape workloads)
-            out["cpu_baseline"] = cpu_baseline(cfg, w)
+        if e2e is not None:
+            out["e2e"] = e2e
+        out.update(cpu_lines)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -258,6 +258,16 @@ def public_view(result):
     return out
 
 
+def raw_confidences(view):
+    """Flat list: per segment its confidence (if any), then its words' confidences."""
+    out = []
+    for s in view["segments"]:
+        if "confidence" in s:
+            out.append(s["confidence"])
+        out.extend(w["confidence"] for w in s["words"] if "confidence" in w)
+    return out
+
+
 # --------------------------------------------------------------------------- reference loading
 def load_reference():
     import whisper_double as W
@@ -295,6 +305,19 @@ def main():
         rec = dict(c)
         rec["expected"] = json.loads(json.dumps(public_view(result), default=float))
         rec["recorded"] = script.record
+        # the same run with the reference's round_confidence (transcribe.py:1807) switched off: confidences before
+        # round(, 3), for the 1e-4 bar on the raw value
+        from whisper_double.decoding import Script
+        model, audio, _ = build_case(c)
+        set_script(Script(script.record))
+        keep = ref.round_confidence
+        ref.round_confidence = lambda x: x
+        try:
+            raw = ref.transcribe_timestamped(model, audio, fp16=False, **c["opts"])
+        finally:
+            ref.round_confidence = keep
+            set_script(None)
+        rec["expected_raw_confidence"] = raw_confidences(json.loads(json.dumps(public_view(raw), default=float)))
         done[c["name"]] = rec
         nw = sum(len(s["words"]) for s in rec["expected"]["segments"])
         print(f"{c['name']:32s} segments={len(rec['expected']['segments'])} words={nw} windows={len(script.record)}")

@@ -93,6 +93,29 @@ def test_dtw_bit_exact_ties_and_masks():
     check_dtw_exact(costs)
 
 
+def test_dtw_bit_exact_positive_and_mixed_sign_costs():
+    """include/wtalign.h promises dtw-python semantics for ANY finite cost, not only the product's (<= 0, cost[0,0] =
+    min).  With cost[0,0] > 0 the first row is where a stale seed of cell (0,0) would show: g[0,j] must be the prefix
+    sum of row 0."""
+    rng = np.random.RandomState(21)
+    costs = [np.ones((3, 7), np.float32), np.array([[2.0, 1.0, 1.0, 5.0], [1.0, 3.0, 0.5, 0.25]], np.float32),
+             rng.rand(1, 40).astype(np.float32), rng.rand(70, 1).astype(np.float32)]
+    for _ in range(60):
+        T = int(rng.choice([1, 2, 5, 31, 64, 65, 130, 224, 256]))
+        F = int(rng.choice([1, 3, 4, 33, 64, 65, 200, 611, 1500]))
+        kind = rng.randint(3)
+        c = rng.rand(T, F) if kind == 0 else rng.standard_normal((T, F)) if kind == 1 else rng.randint(-2, 3, size=(T, F)) / 2.0
+        costs.append(c.astype(np.float32))
+    check_dtw_exact(costs)
+    # and the values themselves on one unit: the distance of a single-row unit is the plain sum of the row
+    row = rng.rand(1, 300).astype(np.float32)
+    (_, _, _, dist), = run_dtw([row])
+    acc = 0.0
+    for v in row[0]:
+        acc += float(v)
+    assert dist == acc
+
+
 def test_dtw_bit_exact_max_sizes():
     rng = np.random.RandomState(2)
     costs = [(-rng.rand(256, 1500)).astype(np.float32), (-rng.rand(224, 1500)).astype(np.float32),
@@ -244,6 +267,18 @@ def test_batch_of_real_shapes_vs_oracle():
         r2 = O.dtw_ref(g)
         assert np.array_equal(jm, O.jumps_from_path(r2.index1s, r2.index2s))
     print(f"max |jump difference| vs oracle end-to-end over 160 units: {worst} frame(s)")
+    # how many units differ at all, and by how much, goes on record next to the profiles (profiles/*_parity_units.json)
+    n_diff = 0
+    for jm, ref in zip(jumps, refs):
+        r = O.dtw_ref(ref)
+        n_diff += int(np.any(jm != O.jumps_from_path(r.index1s, r.index2s)))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_units.json"), "w") as f:
+        json.dump({"test": "test_batch_of_real_shapes_vs_oracle", "units": len(refs), "units_with_jump_diff": n_diff,
+                   "worst_abs_jump_diff_frames": worst,
+                   "note": "GPU cost (fp32, own reduction order) -> GPU DTW vs oracle cost -> oracle DTW; with the GPU's own "
+                           "cost fed to the oracle DTW all units are bit-identical (asserted)"}, f)
     assert worst <= 1
 
 
@@ -326,6 +361,82 @@ def test_logprob_gather_vs_oracle():
     # confidence = exp(mean(logprobs)) within 1e-4 before rounding
     lp_g, lp_o = got.numpy(), want.numpy()
     assert abs(np.exp(lp_g.mean()) - O.confidence_raw_ref(lp_o)) < 1e-4
+
+
+def test_logprob_gather_rows_vs_oracle():
+    """wt_logprob_gather_rows: an explicit (row, token) list over a padded (B * T_max, V) block -- rows repeated,
+    skipped, out of order -- equals the oracle's log_softmax(...)[row, token]; and equals wt_logprob_gather_batch bit
+    for bit on the same rows."""
+    L = _lib()
+    rng = np.random.RandomState(8)
+    for V, n_rows, dtype in [(51865, 96, torch.float32), (51864, 17, torch.float32), (51866, 33, torch.float16)]:
+        logits = torch.from_numpy((rng.standard_normal((n_rows, V)) * 4).astype(np.float32)).to(dtype)
+        idx = rng.randint(0, n_rows, size=150).astype(np.int32)
+        idx[:5] = [n_rows - 1, 0, 0, 7, n_rows - 1]
+        toks = rng.randint(0, V, size=idx.size).astype(np.int32)
+        dl = logits.to(DEV)
+        got = L.logprob_gather_rows(dl, torch.from_numpy(idx).to(DEV), torch.from_numpy(toks).to(DEV)).cpu()
+        want = O.token_logprob_gather_ref(logits.float()[idx.astype(np.int64)], toks)
+        assert (got - want).abs().max() < 2e-5, (V, (got - want).abs().max())
+        same = L.logprob_gather(dl[torch.from_numpy(idx).long().to(DEV)].contiguous(), torch.from_numpy(toks)).cpu()
+        assert torch.equal(got, same)
+    out = torch.full((10,), 7.0, device=DEV)
+    L.logprob_gather_rows(dl, torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV), out=out)
+    assert (out[4:] == 7.0).all() and torch.isfinite(out[:4]).all()
+
+
+def test_qk_rows_batch_vs_torch_and_single_window():
+    """wt_qk_rows_batch (every window, every hooked layer, one launch) == (q * s) @ (k * s)^T in fp32 torch for the
+    selected heads, == wt_qk_rows window by window bit for bit; rows outside [row_begin, row_end) are not touched."""
+    from whisper_timestamped.capture import QKCaptureRing
+    L = _lib()
+    g = torch.Generator().manual_seed(12)
+    H, hd, n_ctx, B, n_q = 6, 64, 1500, 3, 37
+    D = H * hd
+    pairs = [(0, 1), (1, 0), (1, 5), (2, 3), (2, 4)]
+    sel_layer = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=DEV)
+    sel_head = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=DEV)
+    sel_slot = torch.arange(len(pairs), dtype=torch.int32, device=DEV)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float16, 2e-2)):
+        qs = [(torch.randn((B, n_q, D), generator=g) * 0.7).to(dtype).to(DEV) for _ in range(3)]
+        ks = [(torch.randn((B, n_ctx, D), generator=g) * 0.7).to(dtype).to(DEV) for _ in range(3)]
+        ring = torch.full((B, len(pairs), n_q + 2, n_ctx), -77.0, device=DEV)
+        lo = torch.tensor([3, 0, 36], dtype=torch.int32, device=DEV)
+        hi = torch.tensor([37, 20, 37], dtype=torch.int32, device=DEV)
+        L.qk_rows_batch(qs, ks, sel_layer, sel_head, sel_slot, ring, row_begin=lo, row_end=hi, ring_row0=1)
+        torch.cuda.synchronize()
+        scale = hd ** -0.25
+        for b in range(B):
+            single = QKCaptureRing(DEV, pairs, n_hooked_layers=3, n_heads=H, n_ctx=n_ctx, capacity=n_q + 2)
+            for layer in range(3):
+                single.write_from_projections(layer, qs[layer][b:b + 1], ks[layer][b:b + 1], row0=1, n_rows=n_q)
+            for slot, (l, h) in enumerate(pairs):
+                qh = (qs[l][b].float() * scale)[:, h * hd:(h + 1) * hd]
+                kh = (ks[l][b].float() * scale)[:, h * hd:(h + 1) * hd]
+                want = qh @ kh.T                                            # (n_q, n_ctx)
+                a, e = int(lo[b]), int(hi[b])
+                got = ring[b, slot, 1 + a:1 + e]
+                assert (got - want[a:e]).abs().max().item() <= tol
+                assert torch.equal(got, single.buf[slot, 1 + a:1 + e])
+                assert (ring[b, slot, :1 + a] == -77.0).all() and (ring[b, slot, 1 + e:] == -77.0).all()
+    # fp16 ring (storage option)
+    ring16 = torch.zeros((B, len(pairs), n_q, n_ctx), dtype=torch.float16, device=DEV)
+    L.qk_rows_batch(qs, ks, sel_layer, sel_head, sel_slot, ring16)
+    ring32 = torch.zeros((B, len(pairs), n_q, n_ctx), dtype=torch.float32, device=DEV)
+    L.qk_rows_batch(qs, ks, sel_layer, sel_head, sel_slot, ring32)
+    assert torch.equal(ring16, ring32.half())
+
+
+def test_cost_rejects_more_than_256_rows():
+    L = _lib()
+    descs = L.make_descs(1)
+    descs[0]["T"], descs[0]["F"], descs[0]["pad_from"] = 257, 300, -1
+    descs[0]["head_stride"], descs[0]["row_stride"] = 257 * 1500, 1500
+    n_cost, _, _ = L.layout_outputs(descs)
+    qk = torch.zeros((2, 257, 1500), device=DEV)
+    with pytest.raises(L.WtError, match="unsupported shape"):
+        L.cost_batch(qk, descs, L.descs_to_device(descs, DEV), torch.arange(2, dtype=torch.int32, device=DEV),
+                     torch.empty(n_cost, device=DEV))
 
 
 def test_logprob_gather_strided_rows_and_suppressed_token():

@@ -1,0 +1,150 @@
+"""The multi-GPU layer on RCCL (torch.distributed backend "nccl" on ROCm) on a real MI355X.
+
+The gpurun box has ONE GPU, so what can be exercised here is a 1-rank RCCL communicator (every collective of
+whisper_timestamped/sharding.py goes through librccl: broadcast of the flat weight buffers, the asynchronous
+double-buffered result gather, the island job's object gather) and -- if RCCL accepts two ranks on the same device --
+the 2-rank island job of tests/test_sharding_gloo.py on the nccl backend.  The N=2/4/8 scaling run is the driver's.
+"""
+import json
+import os
+import sys
+import time
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from test_sharding_gloo import (_check_islands_result, _free_port, _islands_job, _run_islands_job, _jumps_for, _units)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(rank, world, port):
+    for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    return dist
+
+
+def _one_rank_worker(rank, world, port, out_path):
+    import numpy as np
+    dist = _setup(rank, world, port)
+    from whisper_timestamped.sharding import ResultGatherer, broadcast_module_weights, partition_units
+    dev = torch.device("cuda", 0)
+    report = {"backend": dist.get_backend(), "world": world}
+    try:
+        # 1. flat weight broadcast (one message per dtype) through RCCL
+        import whisper_double as W
+        model = W.build_model("tiny", seed=0, device=dev)
+        before = [p.detach().clone() for p in model.parameters()]
+        t0 = time.perf_counter()
+        broadcast_module_weights(dist, model, src=0)
+        torch.cuda.synchronize()
+        report["broadcast_weights_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        report["broadcast_bytes"] = int(sum(p.numel() * p.element_size() for p in model.parameters()))
+        for a, b in zip(model.parameters(), before):
+            assert torch.equal(a, b)
+
+        # 2. result records: asynchronous, double buffered, 8 steps per message
+        units = _units(23)
+        parts = partition_units([t * f for t, f in units], world)
+        cap_j = max(sum(units[i][0] + 1 for i in p) for p in parts)
+        cap_l = max(sum(units[i][0] for i in p) for p in parts)
+        jumps = torch.full((cap_j,), -1, dtype=torch.int32)
+        lps = torch.zeros(cap_l, dtype=torch.float32)
+        oj = ol = 0
+        for i in parts[rank]:
+            T, F = units[i]
+            j, lp = _jumps_for(i, T, F)
+            jumps[oj:oj + T + 1] = torch.from_numpy(j)
+            lps[ol:ol + T] = torch.from_numpy(lp)
+            oj += T + 1
+            ol += T
+        jumps, lps = jumps.to(dev), lps.to(dev)
+        g = ResultGatherer(dist, cap_j, cap_l, dev, every=8)
+        t0 = time.perf_counter()
+        for step in range(19):                                   # two full messages + a partial one
+            g.gather(jumps if step >= 16 else jumps + step + 1, lps)
+        g.drain()
+        torch.cuda.synchronize()
+        report["gather_19_steps_every_8_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        report["gather_message_bytes"] = int(8 * (cap_j + cap_l) * 4)
+        bj, bl = g.unpack(0, step=0)
+        oj = ol = 0
+        for i in parts[0]:
+            T, F = units[i]
+            j, lp = _jumps_for(i, T, F)
+            assert np.array_equal(bj[oj:oj + T + 1].cpu().numpy(), j) and np.array_equal(bl[ol:ol + T].cpu().numpy(), lp)
+            oj += T + 1
+            ol += T
+
+        # 3. the long-form island job with dist=... (weights broadcast, audio shared, results gathered)
+        job = _islands_job()
+        t0 = time.perf_counter()
+        result, seen = _run_islands_job(dist, job, None, device="cuda:0")
+        report["islands_job_s"] = round(time.perf_counter() - t0, 3)
+        if rank == 0:
+            assert sorted(seen) == ([0, 1, 2, 3] if world == 1 else sorted(seen))
+            dt, dc = _check_islands_result(result, job, time_tol=0.02, conf_tol=1e-3 + 1e-4)
+            report["islands_max_abs_dt_s"], report["islands_max_abs_dconfidence"] = round(dt, 4), round(dc, 5)
+            # what the one object gather of the job carries (the reason it is not a fixed-stride record: it is the
+            # finished transcribe() dictionaries, once per JOB, not the per-step unit records of ResultGatherer)
+            import pickle
+            report["island_results_pickle_bytes"] = len(pickle.dumps(result))
+        owned = [None] * world
+        dist.all_gather_object(owned, seen)
+        assert sorted(i for part in owned for i in part) == [0, 1, 2, 3]
+        if rank == 0:
+            report["islands_per_rank"] = owned
+            with open(out_path, "w") as f:
+                json.dump(report, f)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _keep(report, name):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "w") as f:
+        json.dump(report, f)
+
+
+@pytest.mark.timeout(600)
+def test_sharding_layer_on_a_one_rank_rccl_communicator(tmp_path):
+    out = tmp_path / "rccl1.json"
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), str(out)), nprocs=1, join=True)
+    report = json.loads(out.read_text())
+    assert report["backend"] == "nccl" and report["islands_max_abs_dt_s"] <= 0.02
+    _keep(report, "rccl_one_rank.json")
+
+
+@pytest.mark.timeout(900)
+def test_islands_job_two_ranks_on_one_gpu_if_rccl_allows(tmp_path):
+    """Two processes, both on cuda:0.  RCCL may refuse two ranks on one device ("Duplicate GPU detected"): that is a
+    property of the box (one GPU), not of the code -- the test then skips and says so."""
+    out = tmp_path / "rccl2.json"
+    ctx = mp.spawn(_one_rank_worker, args=(2, _free_port(), str(out)), nprocs=2, join=False)
+    deadline = time.time() + 240            # own bound: a refused communicator must not sit on the GPU box
+    try:
+        while not ctx.join(timeout=5):
+            if time.time() > deadline:
+                for proc in ctx.processes:  # exactly the processes this test started
+                    if proc.is_alive():
+                        proc.kill()
+                _keep({"two_ranks_on_one_gpu": "no answer from RCCL within 240 s (processes killed)"}, "rccl_two_ranks.json")
+                pytest.skip("two ranks on the single GPU of this box: RCCL did not come up")
+    except Exception as e:                                       # noqa: BLE001 -- whatever RCCL raises at init
+        msg = str(e)
+        if any(k in msg for k in ("Duplicate GPU", "NCCL", "nccl", "invalid usage", "unhandled system error", "ncclInvalidUsage")):
+            _keep({"two_ranks_on_one_gpu": "refused by RCCL", "error": msg[-400:]}, "rccl_two_ranks.json")
+            pytest.skip("RCCL does not accept two ranks on the single GPU of this box")
+        raise
+    report = json.loads(out.read_text())
+    assert report["world"] == 2 and all(len(p) > 0 for p in report["islands_per_rank"])
+    _keep(report, "rccl_two_ranks.json")

@@ -19,19 +19,42 @@ from golden import make_golden_transcribe as G
 CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "transcribe_cases.json"), encoding="utf-8"))
 
 
-def run_case(c, device="cpu"):
+def run_case(c, device="cpu", raw_confidence=False):
+    """raw_confidence: confidences BEFORE the reference's round(, 3) (whisper_timestamped.words.RAW_CONFIDENCE)."""
     import whisper_double as W
     from whisper_double.decoding import Script, set_script
     W.install()
     import whisper_timestamped as wt
+    from whisper_timestamped import words
     model, audio, _ = G.build_case(c, device=device)
     script = set_script(Script(c["recorded"]))       # replay exactly what the reference run sampled
+    words.RAW_CONFIDENCE = bool(raw_confidence)
     try:
         result = wt.transcribe(model, audio, fp16=False, **c["opts"])
     finally:
+        words.RAW_CONFIDENCE = False
         set_script(None)
     assert script.record == c["recorded"]
     return json.loads(json.dumps(G.public_view(result), default=float))
+
+
+def rounded(view):
+    """A raw-confidence view -> what the public call returns (round(, 3) as transcribe.py:1807-1808)."""
+    view = copy.deepcopy(view)
+    for s in view["segments"]:
+        if "confidence" in s:
+            s["confidence"] = round(s["confidence"], 3)
+        for w in s["words"]:
+            if "confidence" in w:
+                w["confidence"] = round(w["confidence"], 3)
+    return view
+
+
+def raw_confidence_gap(view, case):
+    """max |confidence - reference's confidence| before rounding (BASELINE.json: within 1e-4)."""
+    got, want = G.raw_confidences(view), case["expected_raw_confidence"]
+    assert len(got) == len(want)
+    return max((abs(a - b) for a, b in zip(got, want)), default=0.0)
 
 
 def compare(got, exp, time_tol, conf_tol, logprob_tol=1e-4, sampled=False):
@@ -69,8 +92,9 @@ def compare(got, exp, time_tol, conf_tol, logprob_tol=1e-4, sampled=False):
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_transcribe_host_logic_equals_reference(case, monkeypatch):
     cpu_kernel_standin.install(monkeypatch)
-    got = run_case(copy.deepcopy(case))
-    compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+    raw = run_case(copy.deepcopy(case), raw_confidence=True)
+    compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+    assert raw_confidence_gap(raw, case) <= 1e-5      # (batched windows: GEMM batch-size rounding, ~2e-6)
 
 
 def is_sampled(case):

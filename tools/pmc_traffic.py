@@ -3,7 +3,9 @@
 
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
 coalesced streaming read -> it is DOUBLED here; WRITE_SIZE is uncalibrated and taken as is.  Both counters are in KB.
-usage: pmc_traffic.py <fetch.db> <write.db>   -> JSON {kernel: {fetch_bytes, write_bytes, hbm_bytes}}
+usage: pmc_traffic.py <fetch.db> <write.db> [--workload NAME]
+       -> JSON {"_workload": NAME, kernel: {fetch_bytes, write_bytes, hbm_bytes}}
+bench.py only quotes a committed summary whose "_workload" equals the workload it is running.
 """
 import json
 import re
@@ -25,6 +27,8 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {}
+    if "--workload" in sys.argv:
+        out["_workload"] = sys.argv[sys.argv.index("--workload") + 1]
     for k in sorted(set(fetch) | set(write)):
         if "wt" not in k:
             continue

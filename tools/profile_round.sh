@@ -1,22 +1,32 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun):  tools/profile_round.sh <tag>
-# Produces gpurun_out/<tag>/: bench.json (un-profiled), kernel_stats.txt (rocprofv3 --kernel-trace --stats of the same
-# bench command), traffic.json (FETCH_SIZE / WRITE_SIZE PMC passes, separate runs, gfx950 correction applied).
+# Run on the GPU box (through gpurun):  tools/profile_round.sh <tag> [workload]
+# Produces gpurun_out/<tag>/: bench.json (un-profiled default line, e2e leg and CPU baselines included),
+# kernel_stats.txt (rocprofv3 --kernel-trace of the same kernel-level bench command), traffic.json (FETCH_SIZE /
+# WRITE_SIZE PMC passes, separate runs, gfx950 correction applied, tagged with the workload),
+# e2e_kernel_stats.txt (kernel trace of the transcribe()-level leg alone).
 set -u
 tag=${1:-round}
+wl=${2:-kfull}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$ROOT/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py"
-timeout 300 $B --steps 20 --warmup 3 > "$out/bench.json" 2> "$out/bench.err"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- $B --steps 10 --warmup 2 --no-cpu-baseline > "$out/kt.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- $B --steps 3 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o pmc -- $B --steps 3 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1
+B="python $ROOT/bench.py --workload $wl"
+K="$B --e2e off --no-cpu-baseline"
+timeout 600 $B --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- $K --steps 10 --warmup 2 --repeats 5 > "$out/kt.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_write.log" 2>&1
+if [ "$wl" = kfull ]; then
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt_e2e" -o kt -- $B --e2e on --no-cpu-baseline --steps 1 --warmup 1 --repeats 1 --e2e-steps 3 > "$out/kt_e2e.log" 2>&1
+  ke=$(find "$out/kt_e2e" -name "*.db" | head -1)
+  python $ROOT/tools/rocpd_stats.py "$ke" > "$out/e2e_kernel_stats.txt" 2>&1
+fi
 kt=$(find "$out/kt" -name "*.db" | head -1)
 pf=$(find "$out/pmc_fetch" -name "*.db" | head -1)
 pw=$(find "$out/pmc_write" -name "*.db" | head -1)
 python $ROOT/tools/rocpd_stats.py "$kt" --skip 2 > "$out/kernel_stats.txt" 2>&1
-python $ROOT/tools/pmc_traffic.py "$pf" "$pw" > "$out/traffic.json" 2> "$out/traffic.err"
+python $ROOT/tools/pmc_traffic.py "$pf" "$pw" --workload $wl > "$out/traffic.json" 2> "$out/traffic.err"
 find "$out" -name "*.csv" -size +2M -delete
-tail -1 "$out/bench.json"; head -12 "$out/kernel_stats.txt"; cat "$out/traffic.json"
+find "$out" -name "*.db" -size +20M -delete
+tail -1 "$out/bench.json"; head -14 "$out/kernel_stats.txt"; head -30 "$out/e2e_kernel_stats.txt" 2>/dev/null

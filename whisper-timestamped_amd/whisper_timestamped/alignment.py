@@ -148,15 +148,23 @@ def prepare_unit(tokens, attention_weights, tokenizer, use_space=True, mfcc=None
         if mfcc is not None:
             sp = int(_lib.find_start_padding(torch.as_tensor(mfcc).to(device).float().reshape(1, *mfcc.shape[-2:]))[0])
             start_of_padding = None if sp < 0 else sp
+    unit = AlignmentUnit(tokens, qk, start_token, end_token, -1, words, word_pieces, word_ids, punct_counts,
+                         refine_whisper_precision_nframes, unfinished_decoding, detect_disfluencies, tokenizer, tag)
+    return set_padding(unit, start_of_padding)
+
+
+def set_padding(unit: AlignmentUnit, start_of_padding):
+    """transcribe.py:1554-1565: where the zero padding of the window's log-mel starts (find_start_padding; None or a
+    negative value = no padding) -> the unit's pad mask.  Separate from prepare_unit so that a batch can split its
+    tokens into words while the GPU is still computing the log-mel the padding is read from."""
     max_duration = max_duration_from_padding(start_of_padding)
-    pad_from = -1
-    if max_duration:                                           # transcribe.py:1561-1565
-        if start_token >= max_duration:
+    unit.pad_from = -1
+    if max_duration:
+        if unit.start_token >= max_duration:
             logger.warning("Got start time outside of audio boundary")
         else:
-            pad_from = max_duration
-    return AlignmentUnit(tokens, qk, start_token, end_token, pad_from, words, word_pieces, word_ids, punct_counts,
-                         refine_whisper_precision_nframes, unfinished_decoding, detect_disfluencies, tokenizer, tag)
+            unit.pad_from = max_duration
+    return unit
 
 
 class _Slot:

@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import _lib, audio as wt_audio, backend
-from .alignment import AlignmentBatch, Workspace, head_pairs, planned_words, prepare_unit
+from .alignment import AlignmentBatch, Workspace, head_pairs, planned_words, prepare_unit, set_padding
 from .capture import layer_head_slots
 from .confidence import strip_trailing_punctuation
 from .words import AUDIO_SAMPLES_PER_TOKEN, HOP_LENGTH, N_FRAMES
@@ -70,6 +70,7 @@ class _Stage:                       # one sub-batch in flight
     tokens: list = field(default_factory=list)
     checks: list = field(default_factory=list)
     keep: list = field(default_factory=list)           # tensors that must outlive the asynchronous launches
+    marks: list = field(default_factory=list)          # (stage name, event) when the aligner keeps a timeline
 
 
 class BatchedAligner:
@@ -105,6 +106,7 @@ class BatchedAligner:
         self.fused = efficient.FUSED_ATTENTION if fused_attention is None else fused_attention
         self.n_mels = model.dims.n_mels if hasattr(model.dims, "n_mels") else 80
         self.workspace = Workspace(self.dev)
+        self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
         sot = tokenizer.sot_sequence
         if language and len(sot) == 3:                                   # :1230-1232
             sot = (sot[0], tokenizer.to_language_token(language), sot[2])
@@ -129,6 +131,12 @@ class BatchedAligner:
         host = _lib.pinned(torch.from_numpy(np.ascontiguousarray(array, dtype=np.int32)))
         keep.append(host)
         return host.to(self.dev, non_blocking=True)
+
+    def _mark(self, st, name):
+        if self.timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+            st.marks.append((name, ev))
 
     # ------------------------------------------------------------------ device: one sub-batch, nothing waits
     def launch(self, jobs) -> _Stage:
@@ -156,9 +164,11 @@ class BatchedAligner:
                 pcm[b, :n_valid[b]].copy_(job.pcm.reshape(-1), non_blocking=True)
             small = self._to_device(np.concatenate([tok_mat.reshape(-1), n_valid]), st.keep)
             tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
+            self._mark(st, "start")
             # log-mel of every crop, zero padded to 3000 frames (:1211-1215), and where the padding starts (:1795-1805)
             mel = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES)
             pad_copy = _lib.HostCopy(_lib.find_start_padding(mel))
+            self._mark(st, "logmel")
             del pcm
             # encoder + teacher-forced decoder on the whole batch (:1236-1238); no logit filters on this path (:1245)
             q_out, k_out, captured = [None] * len(self.hooked), [None] * len(self.hooked), [None] * len(self.hooked)
@@ -177,6 +187,7 @@ class BatchedAligner:
             finally:
                 for h in hooks:
                     h.remove()
+            self._mark(st, "model")
             # the alignment heads' QK rows of every window: (B, A, T_max, 1500)
             ring = torch.empty((B, self.n_slots, T_max, self.n_ctx), dtype=self.ring_dtype, device=dev)
             lens = np.array([len(t) for t in fed], dtype=np.int32)
@@ -188,20 +199,18 @@ class BatchedAligner:
                 for l, h, s in zip(self.sel_layer.tolist(), self.sel_head.tolist(), self.sel_slot.tolist()):
                     ring[:, s].copy_(captured[l][:, h])
             del q_out, k_out, captured
-            # host: units (needs where the padding starts: long since on the host, the wait does not drain the GPU)
-            pad_host = pad_copy.wait()
+            self._mark(st, "qk_rows")
+            # host, while the GPU is busy with the forward pass: tokens -> words, descriptors, which log-probs to read
             n_gather = 0
             gather_rows, gather_toks = [], []
             for b, (job, toks) in enumerate(zip(st.jobs, fed)):
                 end_token = tk.timestamp_begin + round(min(N_SAMPLES, job.n_crop_samples) // AUDIO_SAMPLES_PER_TOKEN)   # :1240
                 utoks = toks[i_start:] + [end_token]
                 st.tokens.append(utoks)
-                sp = int(pad_host[b])
                 unit = prepare_unit(utoks, None, tk, use_space=self.use_space,
                                     refine_whisper_precision_nframes=self.refine,
                                     remove_punctuation_from_words=self.remove_punct, detect_disfluencies=self.disfl,
-                                    start_of_padding=None if sp < 0 else sp,
-                                    qk_selected=ring[b, :, i_start - 1:len(toks)])
+                                    start_of_padding=None, qk_selected=ring[b, :, i_start - 1:len(toks)])
                 st.units.append(unit)
                 plan = []
                 if unit is not None and self.want_conf:
@@ -219,15 +228,21 @@ class BatchedAligner:
                         n_gather += len(kept)
                         i_tok += len(pieces)
                 st.plans.append(plan)
+            # where each window's zero padding starts: queued right behind the log-mel, long since on the host
+            pad_host = pad_copy.wait()
             batch = AlignmentBatch(workspace=self.workspace, extra_words=n_gather)
-            for u in st.units:
+            for b, u in enumerate(st.units):
+                if u is not None:
+                    set_padding(u, None if int(pad_host[b]) < 0 else int(pad_host[b]))
                 batch.add(u)
             batch.launch()
+            self._mark(st, "align")
             if n_gather and batch.units:
                 gt = self._to_device(np.concatenate([np.asarray(gather_rows, dtype=np.int32),
                                                       np.asarray(gather_toks, dtype=np.int32)]), st.keep)
                 _lib.logprob_gather_rows(logits.reshape(B * T_max, -1), gt[:n_gather], gt[n_gather:],
                                          out=batch.extra.view(torch.float32))
+            self._mark(st, "logprob")
             batch.fetch()
             st.batch = batch
             st.keep.extend([ring, logits, tok_dev])
@@ -256,6 +271,8 @@ class BatchedAligner:
                         wl.append(torch.empty(0))
             out.append(WindowResult(ws, wl, utoks, first, last, job.tag))
         st.keep.clear()
+        if self.timeline is not None and st.marks:
+            self.timeline.append({b[0]: a[1].elapsed_time(b[1]) for a, b in zip(st.marks[:-1], st.marks[1:])})
         return out
 
 
