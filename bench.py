@@ -489,13 +489,13 @@ def run_e2e(dev, args, rank, world, dist):
     res32, fp32 = timed(aligner, "fp32")
     out.update(fp32)
     out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
-    # the reference's GPU default is fp16=True: same pipeline with the model and its input in half precision
-    model16 = W.build_model("base", seed=0, device=dev).half()
-    if hasattr(model16, "alignment_heads"):
-        del model16.alignment_heads
-    _, fp16 = timed(BatchedAligner(model16, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
+    # the reference's GPU default is fp16=True (transcribe.py:240-241): the same pipeline with half-precision
+    # activations -- whisper keeps LayerNorm in fp32 and casts the other weights per call; here they are cast once
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
+            m.half()
+    _, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
     out["fp16_model"] = fp16
-    del model16
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same chunks through the reference-shaped CPU path, bounded sample

@@ -365,8 +365,8 @@ def test_logprob_gather_vs_oracle():
 
 def test_logprob_gather_rows_vs_oracle():
     """wt_logprob_gather_rows: an explicit (row, token) list over a padded (B * T_max, V) block -- rows repeated,
-    skipped, out of order -- equals the oracle's log_softmax(...)[row, token]; and equals wt_logprob_gather_batch bit
-    for bit on the same rows."""
+    skipped, out of order -- equals the oracle's log_softmax(...)[row, token], and wt_logprob_gather_batch on a
+    copy of the same rows (up to summation order: the 16-byte alignment of a row decides its head/body/tail split)."""
     L = _lib()
     rng = np.random.RandomState(8)
     for V, n_rows, dtype in [(51865, 96, torch.float32), (51864, 17, torch.float32), (51866, 33, torch.float16)]:
@@ -379,7 +379,7 @@ def test_logprob_gather_rows_vs_oracle():
         want = O.token_logprob_gather_ref(logits.float()[idx.astype(np.int64)], toks)
         assert (got - want).abs().max() < 2e-5, (V, (got - want).abs().max())
         same = L.logprob_gather(dl[torch.from_numpy(idx).long().to(DEV)].contiguous(), torch.from_numpy(toks)).cpu()
-        assert torch.equal(got, same)
+        assert (got - same).abs().max() < 1e-5
     out = torch.full((10,), 7.0, device=DEV)
     L.logprob_gather_rows(dl, torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV), out=out)
     assert (out[4:] == 7.0).all() and torch.isfinite(out[:4]).all()
