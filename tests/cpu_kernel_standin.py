@@ -53,8 +53,17 @@ def install(monkeypatch):
     monkeypatch.setattr(_lib, "logmel", logmel)
 
     def launch(self):
+        # like the real launch, this reads the units' QK rows NOW (later tokens may overwrite the capture ring)
         self._launched = True
         self.extra = torch.zeros(self.extra_words, dtype=torch.int32) if self.extra_words else None
+        self._numbers = []
+        for u in self.units:
+            sel = u.qk[:, :, u.start_token:u.end_token].contiguous().float().numpy()
+            pad = u.pad_from if u.pad_from >= 0 else None
+            cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
+            r = O.dtw_ref(cost)
+            jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
+            self._numbers.append((jumps, O.jumps_start_ref(cost, jumps) if u.detect_disfluencies else None))
         return self
 
     def fetch(self):
@@ -64,15 +73,7 @@ def install(monkeypatch):
 
     def collect(self):
         self.fetch()
-        out = []
-        for u in self.units:
-            sel = u.qk[:, :, u.start_token:u.end_token].contiguous().float().numpy()
-            pad = u.pad_from if u.pad_from >= 0 else None
-            cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
-            r = O.dtw_ref(cost)
-            jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
-            starts = O.jumps_start_ref(cost, jumps) if u.detect_disfluencies else None
-            out.append(alignment.finish_unit(u, jumps, starts))
+        out = [alignment.finish_unit(u, jumps, starts) for u, (jumps, starts) in zip(self.units, self._numbers)]
         self.extra_host = self.extra.numpy() if self.extra is not None else None
         return out
     monkeypatch.setattr(alignment.AlignmentBatch, "launch", launch)

@@ -185,6 +185,39 @@ def test_transcribe_with_the_reference_attention_path(monkeypatch):
         _report(name + "[unfused attention]", dt, dc)
 
 
+def test_transcribe_aligning_segment_by_segment(monkeypatch):
+    """efficient.DEFER_ALIGNMENT = False: a synchronous alignment per flushed segment, as the reference does."""
+    from whisper_timestamped import efficient
+    monkeypatch.setattr(efficient, "DEFER_ALIGNMENT", False)
+    for name in ("two_windows_prompted", "no_trust_whisper_timestamps", "eot_without_end_timestamp"):
+        case = _by_name(name)
+        got = run_case(case, device="cuda:0")
+        dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
+        _report(name + "[segment by segment]", dt, dc)
+
+
+def test_fused_attention_self_check_catches_a_backend_with_another_scaling(monkeypatch):
+    """The once-per-session check of the fused path against the backend's own unfused attention: a backend whose
+    attention scales differently from d_head ** -0.25 on q and k must be refused loudly, not aligned on wrong rows."""
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_script
+    W.install()
+    import whisper_timestamped as wt
+    case = _by_name("one_window_two_segments")
+    model, audio, _ = G.build_case(case, device="cuda:0")
+    orig = W.model.MultiHeadAttention.qkv_attention
+
+    def other_scaling(self, q, k, v, mask=None):
+        return orig(self, q * 1.5, k, v, mask)
+    monkeypatch.setattr(W.model.MultiHeadAttention, "qkv_attention", other_scaling)
+    set_script(Script(case["recorded"]))
+    try:
+        with pytest.raises(RuntimeError, match="FUSED_ATTENTION self-check failed"):
+            wt.transcribe(model, audio, fp16=False, **case["opts"])
+    finally:
+        set_script(None)
+
+
 def test_islands_job_matches_reference_per_island():
     """BASELINE config 4's shape (long recording, speech islands as the sharding unit) on one GPU: every island must
     equal the reference's transcribe() of that crop (tests/golden/islands_job.json); the 2-rank path is covered on

@@ -114,3 +114,15 @@ def test_reusing_the_decoder_logits_gives_the_same_result(case, monkeypatch):
     monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", True)
     got = run_case(copy.deepcopy(case))
     compare(got, case["expected"], time_tol=0.0, conf_tol=1e-3 + 1e-9, logprob_tol=1e-5)
+
+
+def test_segment_by_segment_alignment_gives_the_same_result(monkeypatch):
+    """efficient.DEFER_ALIGNMENT = False: one synchronous alignment per flushed segment (the reference's shape) instead of
+    one launch set per window read a window later -- same output."""
+    from whisper_timestamped import efficient
+    cpu_kernel_standin.install(monkeypatch)
+    monkeypatch.setattr(efficient, "DEFER_ALIGNMENT", False)
+    for name in ("two_windows_prompted", "no_trust_whisper_timestamps", "decoding_limit", "no_speech_skip"):
+        case = next(c for c in CASES if c["name"] == name)
+        got = run_case(copy.deepcopy(case))
+        compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)

@@ -7,7 +7,11 @@ Times, for one 30 s clip and a scripted ~110-token transcript on a whisper-base-
                whisper.model.disable_sdpa(), the only way the reference can get it)
   timestamped: this repository's transcribe() (wt_qk_rows + filtered-logit ring + HIP alignment per segment)
   reuse      : the same with efficient.REUSE_DECODER_LOGITS (no second projection + filter pass per token)
+  per_segment: timestamped with efficient.DEFER_ALIGNMENT = False (one synchronous alignment per flushed segment)
 Prints one JSON line.  The decode loop itself is the backend's Python loop (batch 1), as with the reference.
+
+usage: bench_transcribe.py [base|small|...] [--only plain|timestamped|unfused|reuse|per_segment]
+       (--only: that variant alone, for a rocprofv3 --kernel-trace of exactly one data plane)
 """
 import json
 import os
@@ -31,7 +35,11 @@ from whisper_timestamped import efficient  # noqa: E402
 
 def main():
     dev = "cuda:0"
-    name = sys.argv[1] if len(sys.argv) > 1 else "base"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    if only:
+        args = [a for a in args if a != only]
+    name = args[0] if args else "base"
     model = W.build_model(name, seed=0, device=dev)
     g = torch.Generator().manual_seed(5)
     audio = (0.05 * torch.randn(30 * 16000, generator=g)).float()
@@ -53,6 +61,19 @@ def main():
             best = dt if best is None else min(best, dt)
         return best, out
 
+    if only:
+        def variant():
+            if only == "plain":
+                with torch.no_grad():
+                    return model.transcribe(audio, language="en", temperature=0.0, fp16=False)
+            efficient.FUSED_ATTENTION = only != "unfused"
+            efficient.REUSE_DECODER_LOGITS = only == "reuse"
+            efficient.DEFER_ALIGNMENT = only != "per_segment"
+            return wt.transcribe(model, audio, language="en", fp16=False)
+        t, _ = timed(variant, reps=4)
+        print(json.dumps(dict(model=f"whisper-{name} shapes (random init)", variant=only, tokens=n_tokens, runs=4,
+                              best_s=round(t, 4), ms_per_token=round(1e3 * t / n_tokens, 3))))
+        return
     with torch.no_grad():
         t_plain, _ = timed(lambda: model.transcribe(audio, language="en", temperature=0.0, fp16=False))
     efficient.FUSED_ATTENTION = False             # the reference's way: every attention module unfused, qk observed
@@ -62,12 +83,17 @@ def main():
     efficient.REUSE_DECODER_LOGITS = True
     t_reuse, res2 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
     efficient.REUSE_DECODER_LOGITS = False
+    efficient.DEFER_ALIGNMENT = False
+    t_seg, res3 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    efficient.DEFER_ALIGNMENT = True
     words = sum(len(s.get("words", [])) for s in res["segments"])
     starts = lambda r: [(w["start"], w["end"]) for s in r["segments"] for w in s["words"]]  # noqa: E731
-    same = starts(res) == starts(res2) == starts(res0)
+    same = starts(res) == starts(res2) == starts(res0) == starts(res3)
     print(json.dumps(dict(model=f"whisper-{name} shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
                           plain_s=round(t_plain, 4), timestamped_unfused_attention_s=round(t_unfused, 4),
                           timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
+                          timestamped_per_segment_sync_s=round(t_seg, 4),
+                          overhead_per_segment_sync_pct=round(100 * (t_seg / t_plain - 1), 1),
                           overhead_unfused_attention_pct=round(100 * (t_unfused / t_plain - 1), 1),
                           overhead_pct=round(100 * (t_ts / t_plain - 1), 1),
                           overhead_reuse_pct=round(100 * (t_reuse / t_plain - 1), 1),

@@ -389,13 +389,14 @@ def detect_disfluences(unit: AlignmentUnit, jumps, jumps_start):
     return jumps_start, disfluences
 
 
-def planned_words(unit: AlignmentUnit):
-    """(pieces, ids) of the words ``finish_unit`` will return for this unit, in order, known BEFORE the kernels run:
-    which words exist is decided by the token split alone (words.words_from_jumps drops the timestamp words and
-    "<|...|>" texts; a disfluency mark "[*]" may be inserted later but carries no tokens)."""
+def planned_words(unit: AlignmentUnit, with_text: bool = False):
+    """(pieces, ids) -- or (text, pieces, ids) -- of the words ``finish_unit`` will return for this unit, in order, known
+    BEFORE the kernels run: which words exist is decided by the token split alone (words.words_from_jumps drops the
+    timestamp words and "<|...|>" texts; a disfluency mark "[*]" may be inserted later but carries no tokens)."""
     keep = slice(1, None) if unit.unfinished_decoding else slice(1, -1)
-    return [(pieces, ids) for text, pieces, ids in zip(unit.words[keep], unit.word_pieces[keep], unit.word_ids[keep])
+    rows = [(text, pieces, ids) for text, pieces, ids in zip(unit.words[keep], unit.word_pieces[keep], unit.word_ids[keep])
             if not text.startswith("<|")]
+    return rows if with_text else [(p, i) for _, p, i in rows]
 
 
 def finish_unit(unit: AlignmentUnit, jumps, jumps_start=None):

@@ -97,6 +97,17 @@ class QKCaptureRing:
                                       heads.numel(), self.buf.data_ptr(), self._dt, self.capacity, int(row0), st)
         _lib._check(rc, "wt_qk_rows")
 
+    def write_all_layers(self, q_layers, k_layers, row: int):
+        """ONE launch for every hooked layer (wt_qk_rows_batch with a single window): the LAST query row of each
+        layer's q (1, n_q, D) against its K (1, n_ctx, D) -> ring row `row` of every selected head."""
+        if self.n_slots == 0:
+            return
+        if not hasattr(self, "_sel"):
+            sel = [(l, h, s) for l, (hs, ss) in enumerate(zip(self._heads, self._slots)) for h, s in zip(hs.tolist(), ss.tolist())]
+            self._sel = tuple(torch.tensor([x[i] for x in sel], dtype=torch.int32, device=self.device) for i in range(3))
+        qs = [q[:, -1:, :] for q in q_layers]
+        _lib.qk_rows_batch(qs, k_layers, *self._sel, self.buf.unsqueeze(0), ring_row0=int(row))
+
     def rows(self, rows) -> torch.Tensor:
         """(A_sel, len(rows), n_ctx): a strided VIEW when the rows are consecutive, else a device gather."""
         rows = list(rows)
@@ -117,6 +128,14 @@ class LogitsRing:
     def append(self, logits_row: torch.Tensor):
         """logits_row: (V,) or (1,V) filtered logits (suppressed entries = -inf) of the step just computed."""
         self.buf[self.n].copy_(logits_row.reshape(-1))
+        self.n += 1
+
+    def next_row(self) -> torch.Tensor:
+        """(1, V) view of the row the next step goes to: the caller computes the step's logits straight INTO the ring
+        (``torch.matmul(..., out=row)``), filters them in place, then calls ``commit()`` -- no per-token copy."""
+        return self.buf[self.n:self.n + 1]
+
+    def commit(self):
         self.n += 1
 
     def __len__(self):

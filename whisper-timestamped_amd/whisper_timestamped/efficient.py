@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, backend
-from .alignment import AlignmentBatch, head_pairs, prepare_unit
+from .alignment import AlignmentBatch, Workspace, head_pairs, planned_words, prepare_unit, set_padding
 from .capture import LogitsRing, QKCaptureRing
 from .confidence import segment_confidences
 from .words import HOP_LENGTH, N_AUDIO_CTX, SAMPLE_RATE
@@ -47,6 +47,11 @@ REUSE_DECODER_LOGITS = False
 # unfused path: it runs EVERY attention module of the model (encoder included) unfused, inside
 # whisper.model.disable_sdpa().  False = exactly that (the reference's attention arithmetic for the whole model).
 FUSED_ATTENTION = True
+# Align the segments of a 30 s window with ONE launch set when the window closes, and read the (KB-sized) result
+# record one window later, instead of one launch set + one device->host wait per segment: the words' texts and
+# tokens are known from the token split alone, only their times are filled in later.  Off (or detect_disfluencies,
+# whose "[*]" words only exist after the kernels ran) = the reference's shape, a synchronous alignment per segment.
+DEFER_ALIGNMENT = True
 
 
 class EfficientSession:
@@ -110,6 +115,17 @@ class EfficientSession:
         self.pending_logits = None
         self._q = [None] * len(self.hooked_blocks)
         self._k = [None] * len(self.hooked_blocks)
+        self._v = [None] * len(self.hooked_blocks)     # only until the fused path has been checked once
+        self._fused_checked = False
+        # deferred alignment: units queued during the window, launched when it closes, collected one window later
+        self.defer = DEFER_ALIGNMENT and not detect_disfluencies
+        self.workspace = Workspace(dev)
+        self.queued = []                 # [(unit, placeholder words, padding handle)] of the window being decoded
+        self.in_flight = []              # [(AlignmentBatch, [placeholder word lists])] launched, not yet read
+        self._pad_handles = {}           # id(mfcc) -> (mfcc, HostCopy of find_start_padding): queued when the mel appears
+        # every decoder input of the window, device resident (the logit filters' `tokens` argument)
+        self.ctx_buf = torch.zeros((1, 2 * self.n_ctx + 8), dtype=torch.int64, device=dev)
+        self.ctx_len = 0
 
     # ------------------------------------------------------------------ small predicates
     def _is_sot(self, cur):
@@ -128,6 +144,19 @@ class EfficientSession:
         self.new_mfcc = ins[0]
         if self.mfcc is None:
             self.mfcc = self.new_mfcc
+        if self.defer:                    # where this window's zero padding starts: on the host long before it is needed
+            self._pad_handles = {k: v for k, v in self._pad_handles.items() if v[0] is self.mfcc}
+            self._padding_handle(self.new_mfcc)
+
+    def _padding_handle(self, mfcc):
+        """(mfcc, asynchronous host copy of find_start_padding(mfcc)) -- queued once per window's mel."""
+        if mfcc is None:
+            return None
+        h = self._pad_handles.get(id(mfcc))
+        if h is None or h[0] is not mfcc:
+            h = (mfcc, _lib.HostCopy(_lib.find_start_padding(mfcc.float().reshape(1, *mfcc.shape[-2:]))))
+            self._pad_handles[id(mfcc)] = h
+        return h
 
     def hook_tokens(self, layer, ins, outs):
         cur = ins[0]
@@ -156,6 +185,8 @@ class EfficientSession:
             self.open_rows.append(self.row_next)
             self.row_next += 1
             self.window_inputs.append(cur)
+            self.ctx_buf[0, self.ctx_len:self.ctx_len + len(cur)] = ins[0][0]      # device -> device, no host list
+            self.ctx_len += len(cur)
             if not sot:
                 self.window_tokens_nosot.append(cur[-1])
 
@@ -168,8 +199,38 @@ class EfficientSession:
         self.ring.write(index, qk, self.open_rows[-1])
 
     def hook_cross_attention_fused(self, index, layer, ins, outs):
-        if self.has_started:
-            self.ring.write_from_projections(index, self._q[index], self._k[index], self.open_rows[-1])
+        # the last hooked layer has run: q / K of every hooked layer are known -> ONE launch for all of them
+        if self.has_started and index == len(self.hooked_blocks) - 1:
+            self.ring.write_all_layers(self._q, self._k, self.open_rows[-1])
+            if not self._fused_checked:
+                self._check_fused_rows(self.open_rows[-1])
+
+    def _check_fused_rows(self, row):
+        """Once per session: the rows wt_qk_rows computes from cross_attn.query / cross_attn.key must be the qk the
+        BACKEND's own unfused attention returns for the same projections (MultiHeadAttention.qkv_attention inside
+        disable_sdpa(), what the reference reads, transcribe.py:783-793) -- this is what guards the hook points, the
+        head layout and the d_head ** -0.25 scaling against a backend version that does things differently."""
+        self._fused_checked = True
+        worst = 0.0
+        with torch.no_grad(), backend.attention_weights_exposed(True):
+            for index, b in enumerate(self.hooked_blocks):
+                heads = self.ring._heads[index]
+                if heads.numel() == 0 or self._v[index] is None:
+                    continue
+                ca = self.model.decoder.blocks[b].cross_attn
+                out = ca.qkv_attention(self._q[index][:, -1:], self._k[index], self._v[index])
+                qk = out[1] if isinstance(out, tuple) and len(out) > 1 else None
+                if qk is None:          # this backend cannot show its qk: nothing to compare against
+                    continue
+                want = qk[0, heads.long(), -1].float()                          # (n_sel, n_ctx)
+                got = self.ring.buf[self.ring._slots[index].long(), row].float()
+                worst = max(worst, float((got - want).abs().max()))
+        self._v = [None] * len(self.hooked_blocks)
+        tol = 2e-3 if self._q[0].dtype == torch.float32 else 0.1
+        if not worst <= tol:
+            raise RuntimeError(f"FUSED_ATTENTION self-check failed: the QK rows computed from cross_attn.query/key differ "
+                               f"from the backend's own unfused attention by {worst:.3g} (> {tol}); set "
+                               f"whisper_timestamped.efficient.FUSED_ATTENTION = False for this backend")
 
     def hook_decoder_logits(self, layer, ins, outs):
         """REUSE_DECODER_LOGITS: forward hook on model.decoder; outs = (1, n_q, V) fp32 logits, not yet filtered."""
@@ -211,11 +272,15 @@ class EfficientSession:
             probs = row[lo:lo + len(tk.all_language_tokens)].softmax(dim=-1)
             self.language_probs = dict(zip(backend.whisper().tokenizer.LANGUAGES, probs.tolist()))
         if self.has_started:
-            logits = (x[-1:, :] @ self.embedding_t).float()
-            context = torch.tensor([t for inp in self.window_inputs for t in inp], device=logits.device).unsqueeze(0)
+            logits = self.logits.next_row()                   # the step's row of the device ring: written in place
+            if x.dtype == torch.float32:
+                torch.matmul(x[-1:, :], self.embedding_t, out=logits)
+            else:
+                logits.copy_(x[-1:, :] @ self.embedding_t)     # (half model: one widening pass, as .float() was)
+            context = self.ctx_buf[:, :self.ctx_len]
             for f in self.logit_filters:
                 f.apply(logits, context)
-            self.logits.append(logits)
+            self.logits.commit()
             if self.new_whisper and self._reached_decoding_limit():
                 self.last_chunk_token = self.logits.argmax(-1)
             else:
@@ -311,6 +376,20 @@ class EfficientSession:
 
         if len(tokens) <= 1:
             ws = []
+        elif self.defer:
+            unit = prepare_unit(tokens, None, tk, use_space=backend.should_use_space(self.language),
+                                refine_whisper_precision_nframes=self.refine_nframes,
+                                remove_punctuation_from_words=self.remove_punctuation_from_words,
+                                unfinished_decoding=unfinished, detect_disfluencies=False,
+                                start_of_padding=None, qk_selected=self.ring.rows(rows))
+            if unit is None:
+                ws = []
+            else:
+                # texts and tokens of the words are known now; their times arrive with the window's batch
+                ws = [dict(text=text, start=None, end=None, tokens=pieces, tokens_indices=ids)
+                      for text, pieces, ids in planned_words(unit, with_text=True)]
+                if ws:
+                    self.queued.append((unit, ws, self._padding_handle(self.mfcc)))
         else:
             unit = prepare_unit(tokens, None, tk, use_space=backend.should_use_space(self.language),
                                 refine_whisper_precision_nframes=self.refine_nframes,
@@ -320,7 +399,7 @@ class EfficientSession:
             if unit is None:
                 ws = []
             else:
-                batch = AlignmentBatch()
+                batch = AlignmentBatch(workspace=self.workspace)
                 batch.add(unit)
                 ws = batch.run()[0]
         added = len(ws) > 0
@@ -328,6 +407,38 @@ class EfficientSession:
             self.words_per_segment.append(ws)
         self._reset_open(added, not self._is_sot(cur))
         return added, unfinished, reliable
+
+    # ------------------------------------------------------------------ deferred alignment
+    def _launch_queued(self):
+        """The window is closed: ONE launch set for all of its segments (their QK rows are still in the ring: the
+        kernels are queued on the stream before the next window's tokens overwrite them), then read the PREVIOUS
+        window's record -- that copy was queued a whole window ago, the wait does not stall anything."""
+        previous, self.in_flight = self.in_flight, []
+        if self.queued:
+            batch = AlignmentBatch(workspace=self.workspace)
+            for unit, _, handle in self.queued:
+                if handle is not None:
+                    sp = int(handle[1].wait()[0])
+                    set_padding(unit, None if sp < 0 else sp)
+                batch.add(unit)
+            batch.launch().fetch()
+            self.in_flight.append((batch, [ws for _, ws, _ in self.queued]))
+            self.queued = []
+        self._collect(previous)
+
+    @staticmethod
+    def _collect(batches):
+        for batch, placeholders in batches:
+            for ws, real in zip(placeholders, batch.collect()):
+                assert len(ws) == len(real), f"planned {len(ws)} words, aligned {len(real)}"
+                for w, r in zip(ws, real):
+                    assert w["tokens_indices"] == r["tokens_indices"]
+                    w["start"], w["end"] = r["start"], r["end"]
+
+    def _resolve_all(self):
+        self._launch_queued()
+        pending, self.in_flight = self.in_flight, []
+        self._collect(pending)
 
     # ------------------------------------------------------------------ flush logic
     def _may_flush(self, cur=None):
@@ -339,6 +450,8 @@ class EfficientSession:
             return
         if not self.trust:
             unfinished, reliable = self._align_whole_window(unfinished, reliable)
+        if self.defer:
+            self._launch_queued()
         self.mfcc = self.new_mfcc
         self._close_window(i_start, unfinished, reliable)
 
@@ -385,6 +498,8 @@ class EfficientSession:
         self.segment_tokens[-1] = kept
 
         added, unfinished, reliable = self._align_open_segment()
+        if added and self.defer and not self.use_timestamps_for_alignment:
+            self._resolve_all()                   # (this branch reads word times while re-splitting)
         if added:
             if len(consecutive) > 1:
                 concat = self.words_per_segment[-1]
@@ -491,6 +606,7 @@ class EfficientSession:
                 self.segment_logprobs.append(None)
                 self.segment_avglogprobs.append(None)
         self.window_inputs = []
+        self.ctx_len = 0
         self.window_tokens_nosot = []
         self.logits.reset()
         self.no_speech_prob = None
@@ -506,6 +622,8 @@ class EfficientSession:
                 if FUSED_ATTENTION:
                     hooks.append(ca.query.register_forward_hook(lambda m, i, o, index=j: self._q.__setitem__(index, o)))
                     hooks.append(ca.key.register_forward_hook(lambda m, i, o, index=j: self._k.__setitem__(index, o)))
+                    hooks.append(ca.value.register_forward_hook(
+                        lambda m, i, o, index=j: None if self._fused_checked else self._v.__setitem__(index, o)))
                     hooks.append(ca.register_forward_hook(
                         lambda layer, ins, outs, index=j: self.hook_cross_attention_fused(index, layer, ins, outs)))
                 else:
@@ -524,6 +642,8 @@ class EfficientSession:
                 h.remove()
         self._commit_pending_logits()
         self._may_flush()
+        if self.defer:
+            self._resolve_all()                   # the last window's record
         self.segment_tokens.pop(-1)
         return self._compile(transcription)
 
