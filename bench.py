@@ -544,6 +544,10 @@ def main():
                          "pass BEFORE the timed region (events cannot be read back from inside a graph)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: result records of this many steps travel to rank 0 in one RCCL gather")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="independent batches in flight: step k runs on HIP stream k %% N with its own output buffers (the "
+                         "inputs are shared), so the 32-CU, latency-bound DTW of one step overlaps the other steps' kernels "
+                         "with no cross-stream dependency at all")
     ap.add_argument("--dtw-cus", type=int, default=32, help="--overlap cumask: CUs reserved for the DTW stream")
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel", "cumask"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
@@ -587,13 +591,32 @@ def main():
     elif args.overlap == "cumask":
         streams = ("cumask",) + cu_masked_streams(dev, args.dtw_cus)
 
-    def full_step(ev=None):
+    # --pipeline N: N output-buffer sets over the same inputs, one stream each
+    pipe = [w]
+    pipe_streams = [None]
+    if args.pipeline > 1:
+        assert args.overlap == "none" and not args.graph and gather_buf is None, "--pipeline: plain steps, single rank"
+        n_cost = w["cost"].numel()
+        for _ in range(args.pipeline - 1):
+            c = dict(w)
+            c.pop("_calls", None)
+            c.update(cost=torch.empty(n_cost, dtype=torch.float32, device=dev), mel=torch.empty_like(w["mel"]),
+                     gmax=torch.empty_like(w["gmax"]), pad=torch.empty_like(w["pad"]),
+                     **result_buffers(w["jumps"].numel(), w["logprob"].numel(), dev))
+            pipe.append(c)
+        pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
+
+    def full_step(ev=None, k=0):
+        if args.pipeline > 1:
+            with torch.cuda.stream(pipe_streams[k % args.pipeline]):
+                run_step(pipe[k % args.pipeline], ev, None)
+            return
         run_step(w, ev, streams)
         if gather_buf is not None:
             gather_buf.gather(w["jumps"], w["logprob"])
 
-    for _ in range(args.warmup):
-        full_step()
+    for k in range(max(args.warmup, args.pipeline)):
+        full_step(None, k)
     torch.cuda.synchronize()
 
     graph = None
@@ -631,7 +654,7 @@ def main():
                 graph.replay()
         else:
             for k in range(args.steps):
-                full_step(evs[k])
+                full_step(evs[k], k)
         if gather_buf is not None:
             gather_buf.drain()
         torch.cuda.synchronize()
@@ -659,8 +682,10 @@ def main():
         regions.append(timed_region())
     elapsed = float(np.median(regions))
 
-    # sanity inside the bench: the ridge is recovered and log-probs are finite
+    # sanity inside the bench: the ridge is recovered and log-probs are finite (every buffer set of the pipeline)
     torch.cuda.synchronize()
+    for c in pipe[1:]:
+        assert torch.equal(c["host_result"], w["host_result"]), "pipelined steps disagree with the first buffer set"
     hj = w["host_jumps"].numpy()
     devs = []
     for k, d in enumerate(w["descs"]):
@@ -677,7 +702,8 @@ def main():
         cpu_lines["cpu_baseline_1thread"] = cpu_baseline(cfg, w, budget_s=8.0, threads=1)
 
     e2e = None
-    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
+    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph
+                            and args.pipeline == 1):
         for k in ("qk", "logits", "cost", "mel"):      # the kernel-level inputs are not needed any more
             w[k] = None
         torch.cuda.empty_cache()
@@ -703,7 +729,7 @@ def main():
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
-                       "hip_graph": bool(args.graph),
+                       "hip_graph": bool(args.graph), "batches_in_flight": args.pipeline,
                        "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region",
                        "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the two log-mel kernels on the GPU box: stft_mel_wave_kernel (default) against the workgroup-tile
-stft_mel_kernel (WT_LOGMEL_TILES=1, read once per process -> one subprocess per variant).  Prints one JSON line per
-(variant, batch): mean / min microseconds of wt_logmel_batch (both launches: STFT + finalize) over many calls."""
+"""Timing of wt_logmel_batch alone on the GPU box (both launches: STFT + finalize), several batch sizes: one JSON line
+per (batch, n_mels) with the median / min microseconds over many calls and a checksum of the output (two builds that
+print the same checksum computed the same values).  Round 2 used it for the A/B of the workgroup-tile kernel against
+the wave-autonomous variant (tools/probes/stft_mel_wave_variant.hip, profiles/r2b_logmel_ab.jsonl)."""
 import json
 import os
 import subprocess
@@ -41,8 +42,7 @@ def child():
             b.record()
             torch.cuda.synchronize()
             times.append(a.elapsed_time(b) / reps * 1e3)
-        print(json.dumps(dict(variant=os.environ.get("WT_LOGMEL_TILES") and "workgroup tiles" or "wave autonomous",
-                              n_chunks=n_chunks, n_mels=n_mels, us_median=round(sorted(times)[2], 2), us_min=round(min(times), 2),
+        print(json.dumps(dict(variant=os.environ.get("WT_AB_LABEL", "stft_mel_kernel"), n_chunks=n_chunks, n_mels=n_mels, us_median=round(sorted(times)[2], 2), us_min=round(min(times), 2),
                               checksum=float(mel.double().sum()))), flush=True)
 
 
@@ -50,9 +50,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for tiles in (None, "1", None, "1"):
-            env = dict(os.environ)
-            env.pop("WT_LOGMEL_TILES", None)
-            if tiles:
-                env["WT_LOGMEL_TILES"] = tiles
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=True)
+        for _ in range(2):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ), check=True)

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     double *park = bnd + (size_t)(nw - 1) * bpitch;          // [nw-1][DUMP]
     int *prog = reinterpret_cast<int *>(park + (size_t)(nw - 1) * DUMP);  // [nw-1]
     if (threadIdx.x < nw) prog[threadIdx.x] = 0;
+    // The sweep is a dependency chain fed by ONE wave per SIMD: when another kernel's waves share the SIMD (a second
+    // stream, the next step's kernels) every issue slot they take lengthens the chain.  Highest wave priority: the
+    // arbiter serves this wave first and the others fill the slots it cannot use anyway.
+    __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     WT_STAMP(wave);
 

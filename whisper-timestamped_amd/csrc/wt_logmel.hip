@@ -13,18 +13,20 @@
 // radix-20 butterfly entirely in registers; both stages pair n with 20-n and
 // k with 10-k, and the 20th roots of unity are compile-time constants, so the
 // zeros and +-1 fold away: 324 multiply-adds per lane instead of 1240.  The
-// W400 twiddle comes from a 3.2 KB LDS table, the transposition between the
+// W400 twiddle comes from a 3.2 KB LDS table laid out [n2][k1], the transposition between the
 // two stages goes through LDS.  Three frames per wave, twelve per 256-thread
 // workgroup (39 KB of LDS: 16 waves per CU), 250 workgroups per 30 s chunk.
-// ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT; the kernel is
-// VALU-issue bound (profiles/r1r_sq_counters.txt).
+// ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT.  What bounds it
+// (profiles/r2b_logmel_sq_counters.txt): the two instruction streams themselves -- VALU busy 62 % of the kernel
+// (each wave64 VALU instruction of this mix holds its SIMD for 4 cycles), LDS array busy 55 % (a third of it bank
+// conflicts before the [n2][k1] twiddle table and the padded PCM span) -- not the synchronisation: a persistent,
+// barrier-free, wave-autonomous variant (tools/probes/stft_mel_wave_variant.hip) measured 63 us against 60.
 // Pass 1 writes log10(mel) and one maximum per workgroup (no atomics, nothing
 // to reset); pass 2 reduces them per chunk, applies the clamp/scale and the
 // zero padding.  Algorithmic bytes: 480000*4 read + n_mels*3000*4 written per
 // chunk (the intermediate is re-read from L2).  The banded form of the
 // filterbank is cached per stream and filterbank pointer.
 #include <cmath>
-#include <cstdlib>
 #include <mutex>
 
 #include "wt_common.h"
@@ -137,7 +139,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        float *__restrict__ mel_out) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
-    static_assert(FPB * 204 >= SPAN, "the span must fit in the pw buffer");
+    // The PCM span is stored with every block of 160 samples (one hop) padded to 180 dwords: frames s and s+1 of a wave
+    // then read banks 20 apart instead of the SAME banks (160 = 5 * 32), which made every stage-1 read 2-way conflicted.
+    static_assert(FPB * 204 >= SPAN + ((SPAN - 1) / 160) * 20 + 1, "the padded span must fit in the pw buffer");
     __shared__ float span[FPB * 204];
     __shared__ float2 w400[400];
     __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
@@ -175,18 +179,20 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (i0 >= 0 && i0 + SPAN <= nvs && (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0) {  // block-uniform
         const float4 *src = reinterpret_cast<const float4 *>(x + i0);
         float4 *dst = reinterpret_cast<float4 *>(span);
-        for (int p = tid; p < SPAN / 4; p += 256) dst[p] = src[p];
+        for (int p = tid; p < SPAN / 4; p += 256) dst[p + (p / 40) * 5] = src[p];   // (+20 dwords per 160 samples)
     } else {
         for (int p = tid; p < SPAN; p += 256) {
             int i = i0 + p;
             if (i < 0) i = -i;           // reflect (no edge repeat)
             if (i >= nvs) i = 2 * (nvs - 1) - i;
             i = max(0, min(i, nvs - 1));
-            span[p] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
+            span[p + (p / 160) * 20] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
         }
     }
     for (int p = tid; p < 400; p += 256) hann[p] = k_hann[p];
-    for (int p = tid; p < 400; p += 256) w400[p] = k_w400[p];
+    // twiddles laid out [n2][k1]: the 20 lanes of a frame read 20 consecutive float2 (no bank conflict; W400^(n2*k1)
+    // indexed by its exponent put up to 10 lanes on one bank pair) at an immediate offset per n2 (no address arithmetic)
+    for (int p = tid; p < 400; p += 256) w400[p] = k_w400[(p / 20) * (p % 20)];
     if (tid < n_mels) { fb_lo[tid] = (unsigned char)g_lo[tid]; fb_n[tid] = (unsigned char)g_n[tid]; fb_off[tid] = (unsigned short)g_off[tid]; }
     if (banded)
         for (int p = tid; p < nnz; p += 256) fbw[p] = g_w[p];
@@ -196,9 +202,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         // ---- stage 1: radix-20 over n1 for this lane's n2 = u (real input, k1 = 0..10) ----
         // Pair n1 with 20-n1 (cos even, sin odd) and k1 with 10-k1 ((-1)^n1 symmetry): 108 MACs instead of 440.
         float a[20];
-        const float *fr = span + slot * 160;
+        const float *fr = span + slot * 180;
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hann[20 * n1 + u];
+        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + 20 * (n1 / 8) + u] * hann[20 * n1 + u];
         float ep[10], em[10];
 #pragma unroll
         for (int n = 1; n < 10; ++n) {
@@ -234,14 +240,11 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         typedef float f2 __attribute__((ext_vector_type(2)));
         const f2 cjv = u <= 10 ? (f2){1.f, 1.f} : (f2){1.f, -1.f};   // k1 > 10: the conjugate of row 20 - k1
         f2 B[20];
-        int woff = 0;                        // byte offset of W400^(n2*u) in the table
-        const int wstep = u * (int)sizeof(float2);
+        const float2 *wrow = w400 + u;
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) {
             const float2 vv = yp[slot][ks][n2];
-            const float2 ww = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(w400) + woff);  // (cos, sin)
-            woff += wstep;
-            asm volatile("" : "+v"(woff));   // keep it an add: unrolled, hipcc turns it into n2*u (v_mul_lo_u32: 4x the cost)
+            const float2 ww = wrow[20 * n2];  // (cos, sin) of W400^(n2*u)
             // (re + i im)(cos - i sin) = cos*(re, im) + sin*(im, -re): one packed multiply + one packed fma whose
             // operand modifiers do the swap and the sign (hipcc spends a v_xor and a v_mov on them)
             const f2 v = (f2){vv.x, vv.y} * cjv;
@@ -333,259 +336,6 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (tid == 0) wgmax[(size_t)chunk * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Wave-autonomous version of the same arithmetic (stage 1 / stage 2 / mel projection are the statements above, value for
-// value).  What changes is who waits for whom.  In stft_mel_kernel a workgroup walks one 12-frame tile through four
-// barrier-separated phases, so every wave idles at four barriers per tile and the global reads of a tile are exposed
-// once per tile (SQ counters of round 1: the SIMDs issue VALU 57 % of the time, SQ_WAIT_ANY 52 % of the wave cycles).
-// Here a WAVE owns its three frames from PCM to log-mel:
-//   * its own LDS slice (768 PCM samples + three stage-exchange slots, 8.6 KB); the three frames of a wave never touch
-//     another wave's data, so the only synchronisation inside the loop is the in-order LDS queue of the wave itself
-//     (compiler fences, no s_barrier);
-//   * it is PERSISTENT over `ntw` consecutive triples of a chunk: the hann taps and the W400 twiddles of its lane live in
-//     registers for the whole kernel (they depend on the lane only: 40 LDS reads per frame saved), the banded
-//     filterbank is staged once per workgroup, and the PCM of triple t+1 is already in flight (3 x float4 per lane in
-//     registers) while triple t is transformed;
-//   * the power spectrum of a frame overwrites the frame's own stage-exchange slot (dead by then), and the mel projection
-//     maps lane -> filter (lane and n_mels-1-lane: a narrow and a wide filter per lane balance the tap counts).
-// 8 waves per workgroup, 2 workgroups per CU (72 KB of LDS each): 16 waves per CU as before, none of them at a barrier.
-constexpr int WPB = 8;                       // waves per workgroup
-constexpr int TSPAN = 768;                   // floats staged per triple (2 * 160 + 400 = 720 used; 3 float4 per lane)
-constexpr int YSLOT = 11 * YP;               // float2 per stage-exchange slot (k1 = 0..10, n2 = 0..19 padded to 21)
-struct __attribute__((aligned(16))) WaveLds {
-    float span[TSPAN];
-    float2 yp[3][YSLOT];
-};
-
-__global__ __launch_bounds__(64 * WPB, 4) void stft_mel_wave_kernel(
-    const float *__restrict__ pcm, int64_t n_samples, const int32_t *__restrict__ n_valid_samples,
-    const float *__restrict__ fb, const int *__restrict__ ws, float *__restrict__ wgmax, int n_mels, int n_frames,
-    float *__restrict__ mel_out, int n_chunks, int tri_per_chunk, int groups_per_chunk, int ntw) {
-    __shared__ WaveLds wl[WPB];
-    __shared__ float2 w400[400];
-    __shared__ float hann[400];
-    __shared__ float fbw[NNZ_CAP];
-    __shared__ unsigned char fb_lo[MAX_MELS], fb_n[MAX_MELS];
-    __shared__ unsigned short fb_off[MAX_MELS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int *g_lo = ws, *g_n = g_lo + MAX_MELS, *g_off = g_n + MAX_MELS, *g_tot = g_off + MAX_MELS;
-    const float *g_w = reinterpret_cast<const float *>(g_tot + 1);
-    const int nnz = *g_tot;
-    const bool banded = nnz <= NNZ_CAP;
-    if (tid < n_mels) { fb_lo[tid] = (unsigned char)g_lo[tid]; fb_n[tid] = (unsigned char)g_n[tid]; fb_off[tid] = (unsigned short)g_off[tid]; }
-    if (banded)
-        for (int p = tid; p < nnz; p += 64 * WPB) fbw[p] = g_w[p];
-    if (tid < 400) { w400[tid] = k_w400[tid]; hann[tid] = k_hann[tid]; }
-    __syncthreads();                          // the only barrier of the kernel
-
-    const int gw = blockIdx.x * WPB + wave;   // global wave index -> (chunk, group of ntw triples)
-    const int chunk = gw / groups_per_chunk;
-    const int group = gw - chunk * groups_per_chunk;
-    if (chunk >= n_chunks) return;            // wave-uniform
-    const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
-    const int nvf = min(nvs / 160, n_frames);  // frames kept after dropping the last stft frame
-    const int t_begin = group * ntw;
-    const int t_end = min(min(t_begin + ntw, tri_per_chunk), (nvf + 2) / 3);   // triples that hold at least one real frame
-    float *wg_slot = wgmax + (size_t)chunk * groups_per_chunk + group;
-    if (t_begin >= t_end) {
-        if (lane == 0) *wg_slot = -INFINITY;
-        return;
-    }
-    const float *x = pcm + (int64_t)chunk * n_samples;
-    const bool vec_ok = (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0;
-    const int sub = lane / 20;                // frame slot inside the wave (0..2), lanes 60..63 idle
-    const int u = lane - sub * 20;            // n2 in stage 1, k1 in stage 2
-    float *span = wl[wave].span;
-    float2 *ypw = wl[wave].yp[sub < 3 ? sub : 0];
-
-    // per-lane constants, fetched once: the hann taps 20*n1 + u of this lane (the W400 twiddles stay in an LDS table:
-    // keeping those 40 values in registers as well spills at 4 waves per SIMD)
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const float *hn = hann + u;
-
-    // PCM of one triple: samples [160*3t - 200, +720) of the centre-padded signal.  Interior triples are three
-    // 16-byte loads per lane; the first / last ones of a chunk pay for the reflect arithmetic.
-    // (global_load_lds_dwordx4: HBM/L2 -> LDS without a VGPR round trip, lane l of a load lands at base + 16*l;
-    // completion is tracked by vmcnt)
-    auto interior = [&](int t) { const int i0 = 480 * t - 200; return vec_ok && i0 >= 0 && i0 + TSPAN <= nvs; };
-    auto fetch = [&](int t) {
-        const float *src = x + (480 * t - 200) + 4 * lane;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 256 * k),
-                                             (__attribute__((address_space(3))) void *)(span + 256 * k), 16, 0, 0);
-    };
-    auto gather = [&](int t) {
-        const int i0 = 480 * t - 200;
-        for (int p = lane; p < 720; p += 64) {
-            int i = i0 + p;
-            if (i < 0) i = -i;                 // reflect (no edge repeat)
-            if (i >= nvs) i = 2 * (nvs - 1) - i;
-            i = max(0, min(i, nvs - 1));
-            span[p] = x[i];
-        }
-    };
-
-    if (interior(t_begin)) { fetch(t_begin); wait_vmcnt0(); } else gather(t_begin);
-    wave_lds_fence();
-
-    float lmax = -INFINITY;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int f0 = 3 * t;
-        const bool more = t + 1 < t_end;
-        const bool nx_ok = more && interior(t + 1);   // wave-uniform
-        const bool act = lane < 60 && (f0 + sub) < nvf;
-
-        if (act) {
-            // ---- stage 1 (as in stft_mel_kernel) ----
-            float a[20];
-            const float *fr = span + sub * 160;
-#pragma unroll
-            for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hn[20 * n1];
-            float ep[10], em[10];
-#pragma unroll
-            for (int n = 1; n < 10; ++n) {
-                ep[n] = a[n] + a[20 - n];
-                em[n] = a[n] - a[20 - n];
-            }
-            const float base_e = a[0] + a[10], base_o = a[0] - a[10];
-            float sr[11], si[11];
-#define WT_S1(K)                                                                                          \
-            {                                                                                             \
-                float Ae = 0.f, Ao = 0.f, Be = 0.f, Bo = 0.f;                                             \
-                WT_MAC(Ae, ep[2], c20(2 * K)); WT_MAC(Ae, ep[4], c20(4 * K)); WT_MAC(Ae, ep[6], c20(6 * K));  \
-                WT_MAC(Ae, ep[8], c20(8 * K));                                                            \
-                WT_MAC(Ao, ep[1], c20(1 * K)); WT_MAC(Ao, ep[3], c20(3 * K)); WT_MAC(Ao, ep[5], c20(5 * K));  \
-                WT_MAC(Ao, ep[7], c20(7 * K)); WT_MAC(Ao, ep[9], c20(9 * K));                             \
-                WT_MAC(Be, em[2], s20(2 * K)); WT_MAC(Be, em[4], s20(4 * K)); WT_MAC(Be, em[6], s20(6 * K));  \
-                WT_MAC(Be, em[8], s20(8 * K));                                                            \
-                WT_MAC(Bo, em[1], s20(1 * K)); WT_MAC(Bo, em[3], s20(3 * K)); WT_MAC(Bo, em[5], s20(5 * K));  \
-                WT_MAC(Bo, em[7], s20(7 * K)); WT_MAC(Bo, em[9], s20(9 * K));                             \
-                const float base = (K & 1) ? base_o : base_e;                                             \
-                sr[K] = base + Ae + Ao; sr[10 - K] = base + Ae - Ao;                                      \
-                si[K] = Be + Bo;        si[10 - K] = Bo - Be;                                             \
-            }
-            WT_S1(0) WT_S1(1) WT_S1(2) WT_S1(3) WT_S1(4) WT_S1(5)
-#undef WT_S1
-#pragma unroll
-            for (int k1 = 0; k1 <= 10; ++k1) ypw[k1 * YP + u] = make_float2(sr[k1], -si[k1]);
-        }
-        wave_lds_fence();                              // the frame's 20 lanes exchange through the wave's own LDS slice
-        // The PCM of this triple has been consumed (its reads fed the arithmetic above): the next triple's samples
-        // stream into the same buffer while stage 2 and the mel projection run.
-        if (nx_ok) fetch(t + 1);
-        float pk2[11];
-        if (act) {
-            // ---- stage 2 (as in stft_mel_kernel; twiddles from registers) ----
-            const int ks = u <= 10 ? u : 20 - u;
-            const f2 cjv = u <= 10 ? (f2){1.f, 1.f} : (f2){1.f, -1.f};
-            f2 B[20];
-            int woff = 0;                        // byte offset of W400^(n2*u) in the table
-            const int wstep = u * (int)sizeof(float2);
-#pragma unroll
-            for (int n2 = 0; n2 < 20; ++n2) {
-                const float2 vv = ypw[ks * YP + n2];
-                const float2 ww = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(w400) + woff);
-                woff += wstep;
-                asm volatile("" : "+v"(woff));   // keep it an add (unrolled, hipcc turns it into a v_mul_lo_u32)
-                const f2 v = (f2){vv.x, vv.y} * cjv;
-                const f2 w = (f2){ww.x, ww.y};
-                f2 b = v * (f2){w.x, w.x};
-                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(b) : "v"(v), "v"(w));
-                B[n2] = b;
-            }
-            f2 P[10], D[10];
-#pragma unroll
-            for (int n = 1; n < 10; ++n) {
-                P[n] = B[n] + B[20 - n];
-                D[n] = B[n] - B[20 - n];
-            }
-            const f2 Bev = B[0] + B[10], Bod = B[0] - B[10];
-#define WT_MAC2(acc, x, w)                                                          \
-    do {                                                                            \
-        constexpr float _w = (w);                                                   \
-        if (_w == 1.0f) acc += (x);                                                 \
-        else if (_w == -1.0f) acc -= (x);                                           \
-        else if (_w != 0.0f) acc = __builtin_elementwise_fma((x), (f2){_w, _w}, acc); \
-    } while (0)
-#define WT_S2(K)                                                                                              \
-            {                                                                                                 \
-                f2 CDe = {0.f, 0.f}, CDo = {0.f, 0.f}, SDe = {0.f, 0.f}, SDo = {0.f, 0.f};                    \
-                WT_MAC2(CDe, P[2], c20(2 * K)); WT_MAC2(CDe, P[4], c20(4 * K)); WT_MAC2(CDe, P[6], c20(6 * K));   \
-                WT_MAC2(CDe, P[8], c20(8 * K));                                                               \
-                WT_MAC2(CDo, P[1], c20(1 * K)); WT_MAC2(CDo, P[3], c20(3 * K)); WT_MAC2(CDo, P[5], c20(5 * K));   \
-                WT_MAC2(CDo, P[7], c20(7 * K)); WT_MAC2(CDo, P[9], c20(9 * K));                               \
-                WT_MAC2(SDe, D[2], s20(2 * K)); WT_MAC2(SDe, D[4], s20(4 * K)); WT_MAC2(SDe, D[6], s20(6 * K));   \
-                WT_MAC2(SDe, D[8], s20(8 * K));                                                               \
-                WT_MAC2(SDo, D[1], s20(1 * K)); WT_MAC2(SDo, D[3], s20(3 * K)); WT_MAC2(SDo, D[5], s20(5 * K));   \
-                WT_MAC2(SDo, D[7], s20(7 * K)); WT_MAC2(SDo, D[9], s20(9 * K));                               \
-                const f2 Bk = (K & 1) ? Bod : Bev;                                                            \
-                const f2 U0 = Bk + (CDe + CDo), V0 = SDe + SDo, U1 = Bk + (CDe - CDo), V1 = SDo - SDe;        \
-                const float r0 = U0.x + V0.y, i0 = U0.y - V0.x, r1 = U1.x + V1.y, i1 = U1.y - V1.x;          \
-                pk2[K] = r0 * r0 + i0 * i0; pk2[10 - K] = r1 * r1 + i1 * i1;                                  \
-            }
-            WT_S2(0) WT_S2(1) WT_S2(2) WT_S2(3) WT_S2(4) WT_S2(5)
-#undef WT_S2
-#undef WT_MAC2
-        }
-        // the frame's power spectrum goes where its stage-1 output was: every lane of the wave has issued its reads of
-        // that slot (above, in program order; the LDS queue of a wave is served in order)
-        wave_lds_fence();
-        if (act) {
-            float *pw = reinterpret_cast<float *>(ypw);
-#pragma unroll
-            for (int k2 = 0; k2 < 10; ++k2) pw[u + 20 * k2] = pk2[k2];
-            if (u == 0) pw[200] = pk2[10];   // k = 200 (k1 = 0, k2 = 10)
-        }
-        // The next triple's PCM has had all of stage 2 to arrive.  Waiting for it HERE, before the stores of the mel
-        // projection are issued, keeps those stores out of the wait (vmcnt counts stores too, and cannot be waited on
-        // selectively once loads and stores are mixed).
-        if (nx_ok) wait_vmcnt0();
-        wave_lds_fence();
-
-        // ---- mel projection + log10: lane -> filter lo + lane and filter hi - lane (a narrow and a wide one), the
-        //      three frames of the triple share every tap read ----
-        const float *p0 = reinterpret_cast<const float *>(wl[wave].yp[0]);
-        const float *p1 = reinterpret_cast<const float *>(wl[wave].yp[1]);
-        const float *p2 = reinterpret_cast<const float *>(wl[wave].yp[2]);
-        const int left = nvf - f0;                 // >= 1: frames of this triple that exist
-        for (int lo_m = 0, hi_m = n_mels - 1; lo_m <= hi_m; lo_m += 64, hi_m -= 64) {
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int m = side == 0 ? lo_m + lane : hi_m - lane;
-                const bool ok = side == 0 ? m <= hi_m : m >= lo_m + 64;
-                if (!ok) continue;
-                const int lo = fb_lo[m], n = fb_n[m];
-                const float *w = banded ? fbw + fb_off[m] : fb + m * 201 + lo;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-                for (int k = 0; k < n; ++k) {
-                    const float wk = w[k];
-                    a0 = fmaf(wk, p0[lo + k], a0);
-                    a1 = fmaf(wk, p1[lo + k], a1);
-                    a2 = fmaf(wk, p2[lo + k], a2);
-                }
-                const float L2 = 0.30102999566398120f;
-                const float v0 = __builtin_amdgcn_logf(fmaxf(a0, 1e-10f)) * L2, v1 = __builtin_amdgcn_logf(fmaxf(a1, 1e-10f)) * L2;
-                const float v2 = __builtin_amdgcn_logf(fmaxf(a2, 1e-10f)) * L2;
-                float *out = mel_out + ((int64_t)chunk * n_mels + m) * n_frames + f0;
-                out[0] = v0;
-                lmax = fmaxf(lmax, v0);
-                if (left > 1) { out[1] = v1; lmax = fmaxf(lmax, v1); }
-                if (left > 2) { out[2] = v2; lmax = fmaxf(lmax, v2); }
-            }
-        }
-        wave_lds_fence();                              // the slots are free again
-        if (more && !nx_ok) {
-            gather(t + 1);
-            wave_lds_fence();
-        }
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0) *wg_slot = lmax;
-}
-
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const float *__restrict__ wgmax, int n_wg,
                                                               const int32_t *__restrict__ n_valid_samples, int64_t n_samples,
                                                               int n_mels, int n_frames, float *__restrict__ gmax) {
@@ -641,14 +391,7 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     if (n_chunks == 0) return WT_OK;
     int rc = upload_tables(st);
     if (rc) return rc;
-    // work decomposition of stft_mel_wave_kernel: a wave walks `ntw` consecutive triples (3 frames) of one chunk;
-    // ntw is chosen so that the launch is about one resident set of waves (256 CUs x 16 waves), capped at 8
-    static const bool use_tiles = getenv("WT_LOGMEL_TILES") != nullptr;     // (A/B switch: the workgroup-tile kernel)
-    const int tri_per_chunk = (n_frames + 2) / 3;
-    int ntw = (int)(((int64_t)n_chunks * tri_per_chunk + 4095) / 4096);
-    ntw = ntw < 1 ? 1 : (ntw > 8 ? 8 : ntw);
-    const int groups_per_chunk = (tri_per_chunk + ntw - 1) / ntw;
-    const int n_wg = use_tiles ? (n_frames + FPB - 1) / FPB : groups_per_chunk;
+    const int n_wg = (n_frames + FPB - 1) / FPB;
     const size_t head_ints = 3 * MAX_MELS + 1 + NNZ_CAP;
     int *ws = nullptr;
     bool prepared = false;
@@ -658,13 +401,8 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     // The banded filterbank is cached in the stream's arena: the contents behind `mel_fb` must not change while the
     // same pointer keeps being passed (wt_shutdown() or a different pointer / n_mels rebuilds it).
     if (!prepared) hipLaunchKernelGGL(logmel_init_kernel, dim3(1), dim3(64 * INIT_WAVES), 0, st, ws, mel_fb, n_mels);
-    if (use_tiles)
-        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_wg, n_chunks), dim3(256), 0, st, pcm, n_samples, n_valid_samples, mel_fb, ws,
-                           wgmax, n_mels, n_frames, mel_out);
-    else
-        hipLaunchKernelGGL(stft_mel_wave_kernel, dim3(((int64_t)n_chunks * groups_per_chunk + WPB - 1) / WPB), dim3(64 * WPB), 0,
-                           st, pcm, n_samples, n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_chunks,
-                           tri_per_chunk, groups_per_chunk, ntw);
+    hipLaunchKernelGGL(stft_mel_kernel, dim3(n_wg, n_chunks), dim3(256), 0, st, pcm, n_samples, n_valid_samples, mel_fb, ws,
+                       wgmax, n_mels, n_frames, mel_out);
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, wgmax, n_wg, n_valid_samples,
