@@ -15,6 +15,13 @@ For N>1 every rank owns its own 32 chunks (units are independent: weak
 scaling, no data-path collective); the per-step result records are gathered
 to rank 0 over RCCL, which is where the reference assembles words.
 
+Two batches are in flight by default (--pipeline 2: step k runs on HIP stream
+k % 2 with its own output buffers, no cross-stream dependency): the DTW of a
+32-unit batch occupies 32 of the 256 CUs for a fifth of a step and is a
+latency chain, so the other batch's HBM-bound kernels run beside it.  The
+single-batch-in-flight time is reported in the same line, and the per-stage
+times / roofline are measured in that single-stream pass.
+
 Timing: the region of EXACTLY --steps steps (barrier + synchronize on both sides,
 max over ranks) is repeated until at least --min-seconds of GPU work have been
 timed (never fewer than 5 regions); ms_per_step / value are the MEDIAN region,
@@ -544,10 +551,11 @@ def main():
                          "pass BEFORE the timed region (events cannot be read back from inside a graph)")
     ap.add_argument("--gather-every", type=int, default=8,
                     help="N>1: result records of this many steps travel to rank 0 in one RCCL gather")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="independent batches in flight: step k runs on HIP stream k %% N with its own output buffers (the "
                          "inputs are shared), so the 32-CU, latency-bound DTW of one step overlaps the other steps' kernels "
-                         "with no cross-stream dependency at all")
+                         "with no cross-stream dependency at all.  The line also carries the single-batch-in-flight time; "
+                         "per-stage times and the roofline always come from the single-stream pass")
     ap.add_argument("--dtw-cus", type=int, default=32, help="--overlap cumask: CUs reserved for the DTW stream")
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel", "cumask"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
@@ -578,10 +586,14 @@ def main():
     n = cfg["n_chunks"]
     cfg = w["cfg"]
 
-    gather_buf = None
+    if args.graph or args.overlap != "none":
+        args.pipeline = 1
+    gatherers = None
     if world > 1 or force_dist:
         from whisper_timestamped.sharding import ResultGatherer
-        gather_buf = ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev, every=args.gather_every)
+        gatherers = [ResultGatherer(dist, w["jumps"].numel(), w["logprob"].numel(), dev, every=args.gather_every)
+                     for _ in range(args.pipeline)]
+    gather_buf = gatherers[0] if gatherers else None
 
     streams = None
     if args.overlap == "lanes":
@@ -595,7 +607,6 @@ def main():
     pipe = [w]
     pipe_streams = [None]
     if args.pipeline > 1:
-        assert args.overlap == "none" and not args.graph and gather_buf is None, "--pipeline: plain steps, single rank"
         n_cost = w["cost"].numel()
         for _ in range(args.pipeline - 1):
             c = dict(w)
@@ -606,18 +617,28 @@ def main():
             pipe.append(c)
         pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
 
-    def full_step(ev=None, k=0):
-        if args.pipeline > 1:
-            with torch.cuda.stream(pipe_streams[k % args.pipeline]):
-                run_step(pipe[k % args.pipeline], ev, None)
+    def full_step(ev=None, k=0, pipelined=False):
+        if pipelined:
+            j = k % args.pipeline
+            with torch.cuda.stream(pipe_streams[j]):
+                run_step(pipe[j], ev, None)
+                if gatherers is not None:
+                    gatherers[j].gather(pipe[j]["jumps"], pipe[j]["logprob"])
             return
         run_step(w, ev, streams)
         if gather_buf is not None:
             gather_buf.gather(w["jumps"], w["logprob"])
 
-    for k in range(max(args.warmup, args.pipeline)):
+    for k in range(args.warmup):
         full_step(None, k)
     torch.cuda.synchronize()
+    if args.pipeline > 1:
+        for k in range(max(args.warmup, 2 * args.pipeline)):       # every stream's scratch arenas exist before the timing
+            full_step(None, k, pipelined=True)
+        if gatherers is not None:
+            for g_ in gatherers:
+                g_.drain()
+        torch.cuda.synchronize()
 
     graph = None
     if args.graph:
@@ -643,7 +664,7 @@ def main():
     evs = [make_events() for _ in range(args.steps)]
     stage_samples = {s: [] for s in STAGES}
 
-    def timed_region():
+    def timed_region(pipelined=False):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks; seconds."""
         if dist is not None:
             dist.barrier()
@@ -654,9 +675,10 @@ def main():
                 graph.replay()
         else:
             for k in range(args.steps):
-                full_step(evs[k], k)
-        if gather_buf is not None:
-            gather_buf.drain()
+                full_step(None if pipelined else evs[k], k, pipelined)
+        if gatherers is not None:
+            for g_ in (gatherers if pipelined else gatherers[:1]):
+                g_.drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -665,7 +687,7 @@ def main():
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        if graph is None:
+        if graph is None and not pipelined:
             for s in STAGES:
                 stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
         return el
@@ -676,10 +698,15 @@ def main():
         torch.cuda.synchronize()
         for s in STAGES:
             stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
-    regions = [timed_region()]
-    n_regions = args.repeats or int(min(2000, max(5, np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
-    while len(regions) < n_regions:                  # (every rank derives the same count from the max-reduced first region)
-        regions.append(timed_region())
+    def measure(pipelined):
+        regions = [timed_region(pipelined)]
+        n_regions = args.repeats or int(min(2000, max(5, np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
+        while len(regions) < n_regions:              # (every rank derives the same count from the max-reduced first region)
+            regions.append(timed_region(pipelined))
+        return regions
+
+    single_regions = measure(False)                  # one batch in flight: also the per-stage times and the roofline
+    regions = measure(True) if args.pipeline > 1 else single_regions
     elapsed = float(np.median(regions))
 
     # sanity inside the bench: the ridge is recovered and log-probs are finite (every buffer set of the pipeline)
@@ -702,10 +729,10 @@ def main():
         cpu_lines["cpu_baseline_1thread"] = cpu_baseline(cfg, w, budget_s=8.0, threads=1)
 
     e2e = None
-    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph
-                            and args.pipeline == 1):
-        for k in ("qk", "logits", "cost", "mel"):      # the kernel-level inputs are not needed any more
-            w[k] = None
+    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
+        for c in pipe:                                 # the kernel-level inputs are not needed any more
+            for k in ("qk", "logits", "cost", "mel"):
+                c[k] = None
         torch.cuda.empty_cache()
         e2e = run_e2e(dev, args, rank, world, dist)
 
@@ -735,6 +762,10 @@ def main():
                        "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
                        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
                        "timed_seconds_total": round(float(sum(regions)), 3)},
+            "single_batch_in_flight": {"ms_per_step": round(float(np.median(single_regions)) / args.steps * 1e3, 4),
+                                       "value": round(world * n * 30.0 * args.steps / float(np.median(single_regions)), 1),
+                                       "regions": len(single_regions),
+                                       "note": "one stream, stages back to back: the run the stage times and the roofline below are from"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],

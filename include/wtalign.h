@@ -16,8 +16,11 @@
  *    calls are asynchronous with respect to that stream; nothing synchronises.
  *  - Return value: 0 on success; <0 on error (WT_E_*), with a message
  *    retrievable through wt_last_error() (thread-local).  Nothing throws.
- *  - The library keeps one small lazily-allocated device scratch arena per
- *    device (per-segment reduction words); wt_shutdown() frees it.
+ *  - The library keeps lazily-allocated device scratch arenas per (device,
+ *    stream): per-unit reduction words, the banded mel filterbank, and the DTW's
+ *    direction bit planes (T*F/4 bytes per unit of the largest batch seen);
+ *    wt_shutdown() frees them.  Growing an arena is a hipMalloc: warm a stream
+ *    up once before capturing calls on it into a HIP graph.
  */
 #ifndef WTALIGN_H
 #define WTALIGN_H
@@ -33,9 +36,8 @@ extern "C" {
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
 #define WT_E_HIP (-2)         /* a HIP runtime call failed (see wt_last_error)       */
-#define WT_E_UNSUPPORTED (-3) /* shape outside the kernels' range: T > 256, F > 1792,
-                                 or T > 192 together with F > 1760 (LDS budget of the
-                                 DTW).  The reference never exceeds T <= 226, F <= 1500 */
+#define WT_E_UNSUPPORTED (-3) /* shape outside the kernels' range: T > 256 or F > 1792.
+                                 The reference never exceeds T <= 226, F <= 1500        */
 
 #define WT_DTYPE_F32 0
 #define WT_DTYPE_F16 1

@@ -132,11 +132,19 @@ def test_dtw_rejects_unsupported():
     t = torch.zeros(300 * 100, device=DEV)
     with pytest.raises(L.WtError):
         L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(301, dtype=torch.int32, device=DEV))
-    descs[0]["T"], descs[0]["F"] = 256, 1792      # > 160 KiB of LDS for the direction planes + boundary rows
+    descs[0]["T"], descs[0]["F"] = 256, 1793      # one frame beyond WT_MAX_FRAMES
     L.layout_outputs(descs)
-    t = torch.zeros(256 * 1792, device=DEV)
+    t = torch.zeros(256 * 1793 + 4, device=DEV)
     with pytest.raises(L.WtError):
         L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(257, dtype=torch.int32, device=DEV))
+
+
+def test_dtw_largest_shape_is_supported():
+    """T = 256 with F = 1792: refused in round 1 (direction planes in LDS: > 160 KiB); the planes live in the scratch
+    arena now, so the whole (WT_MAX_TOKENS, WT_MAX_FRAMES) range runs -- several units per launch class."""
+    rng = np.random.RandomState(31)
+    check_dtw_exact([(-rng.rand(256, 1792)).astype(np.float32), (-rng.rand(193, 1790)).astype(np.float32),
+                     (-rng.rand(255, 1761)).astype(np.float32), (-rng.rand(3, 1792)).astype(np.float32)])
 
 
 # ---------------------------------------------------------------------------

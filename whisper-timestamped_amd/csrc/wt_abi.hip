@@ -60,6 +60,7 @@ static int scratch_ex(int purpose, hipStream_t st, size_t bytes, void **out, Are
     return WT_OK;
 }
 int scratch(hipStream_t st, size_t bytes, void **out) { return scratch_ex(0, st, bytes, out, nullptr); }  // cost path
+int scratch_dtw(hipStream_t st, size_t bytes, void **out) { return scratch_ex(2, st, bytes, out, nullptr); }  // DTW planes
 // log-mel path: returns true in *prepared when the arena already holds the preparation tagged (ptr, val)
 int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared) {
     Arena *a = nullptr;

@@ -25,10 +25,17 @@
 // about F + 64*W + 32*(W-1) dependent steps instead of a barrier per
 // anti-diagonal, and a step is issue-bound (one wave = one instruction every
 // ~4 cycles), so the per-step instruction count is what the design minimises.
-// Direction bits (2 per cell) live in LDS only (<= 117 KB); each lane streams
-// its own cost row with a 32-frame register prefetch.  Algorithmic HBM bytes:
-// T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its F+T-cell
-// dependency chain; throughput comes from the batch.
+// Direction bits (2 per cell, two planes) go to a per-unit slot of the library's
+// scratch arena, one coalesced 8-byte store per lane per 32 steps ([block][row]
+// layout: a wave writes 512 contiguous bytes; T*F/4 bytes per unit, written and
+// read back by the same CU, i.e. through its XCD's L2) -- LDS holds only the
+// boundary rows between waves (<= 47 KB), so several units share a CU and the
+// kernels of another stream fit beside a unit (round 1 kept the planes in LDS:
+// 141 KB per K-full unit, one unit per CU and nothing else next to it).  Each
+// lane streams its own cost row with a 32-frame register prefetch.  Algorithmic
+// HBM bytes: T*F*4 read + 4*(T+1) written.  One unit is latency-bound by its
+// F+T-cell dependency chain; throughput comes from the batch.
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -73,7 +80,7 @@ __device__ __forceinline__ void load_blk_tiny(const float *__restrict__ unit, in
     }
 }
 
-__host__ __device__ inline int dtw_pitch(int F) { return ((F + 63 + BLK - 1) / BLK) | 1; }  // words per row per plane
+__host__ __device__ inline int dtw_blocks(int F) { return (F + 63 + BLK - 1) / BLK; }        // 32-step blocks of a sweep
 __host__ __device__ inline int dtw_bnd_pitch(int F) { return (F + 64 + BLK + 1) & ~1; }      // doubles per boundary row (even: 16-byte rows)
 constexpr int DUMP = 64 + BLK;  // doubles per producer wave: where lanes 0..62 park the per-step store only lane 63 needs
 
@@ -95,6 +102,17 @@ __device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1
                  "v_cmp_lt_f64 vcc, %4, %5\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
                  : "+v"(wa), "+v"(wb) : "v"(a1), "v"(a2), "v"(b1), "v"(b2) : "vcc");
 }
+// The two plane words of a finished block -> the unit's scratch slot.  Issued as inline assembly on purpose: a store
+// the compiler knows about would share the vmcnt counter with the cost prefetch, and with loads AND stores pending
+// hipcc waits with vmcnt(0) at the next use of prefetched data -- the memory latency the prefetch exists to hide,
+// once per block.  Unknown to the compiler, the store only makes its counted waits conservative by one (loads return
+// in order among themselves; the store was issued a whole block earlier).  gfx9 reads store data at issue: the
+// registers may be reused at once.  The kernel waits for these stores itself before the backtrack (wait_vmcnt0).
+__device__ __forceinline__ void store_plane_words(const uint2 *base, unsigned voff, uint32_t wa, uint32_t wb) {
+    const uint64_t data = (uint64_t)wa | ((uint64_t)wb << 32);
+    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(data), "s"(base) : "memory");
+}
+
 // One 32-step block of the anti-diagonal sweep.
 // EDGE: this wave has a producer wave above it; edge[k] = g[64w-1, s0+k] (the same value in every lane, read from
 // the boundary row with broadcast LDS loads before the block) becomes the "old" operand of the wave_shr:1 that
@@ -134,7 +152,7 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
 template <bool DIST, bool TINY>
 __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
                            int32_t *__restrict__ path_i, int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
-                           double *__restrict__ dist) {
+                           double *__restrict__ dist, uint2 *planes, long long plane_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const wt_seg_desc d = segs[blockIdx.x];
     const int T = d.T, F = d.F;
@@ -146,11 +164,12 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     const int i = wave * 64 + lane;  // token row
     const bool row_ok = i < T;
     const int nsteps = F + 63;
-    const int pitch = dtw_pitch(F);
     const int bpitch = dtw_bnd_pitch(F);
+    const int rowsP = nw * 64;                               // rows of one block of plane words
 
-    uint2 *plane = reinterpret_cast<uint2 *>(smem);          // [nw*64][pitch] (.x = plane A word, .y = plane B word)
-    double *bnd = reinterpret_cast<double *>(plane + (size_t)nw * 64 * pitch);  // [nw-1][bpitch], bnd[w][64 + j]
+    // [block][row] (.x = plane A word, .y = plane B word) in this unit's slot of the scratch arena
+    uint2 *plane = planes + (size_t)blockIdx.x * plane_stride;
+    double *bnd = reinterpret_cast<double *>(smem);          // [nw-1][bpitch], bnd[w][64 + j]
     double *park = bnd + (size_t)(nw - 1) * bpitch;          // [nw-1][DUMP]
     int *prog = reinterpret_cast<int *>(park + (size_t)(nw - 1) * DUMP);  // [nw-1]
     if (threadIdx.x < nw) prog[threadIdx.x] = 0;
@@ -181,6 +200,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     double *pub = (lane == 63) ? bnd + (size_t)pw * bpitch + 1 : park + (size_t)pw * DUMP + lane;
     const int pubinc = (lane == 63) ? BLK : 0;
     const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
+    unsigned pvoff = 8u * (unsigned)i;                       // byte offset of this lane's word pair in the current block
+    const unsigned pvstep = 8u * (unsigned)rowsP;
 
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
@@ -217,7 +238,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                 }
             }
             sweep_block<EDGE, PUBLISH, DIST, FIRST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-            plane[(size_t)i * pitch + s0 / BLK] = make_uint2(wa, wb);
+            store_plane_words(plane, pvoff, wa, wb);
+            pvoff += pvstep;
             if (PUBLISH) {
                 pub += pubinc;
                 if (lane == 0) {
@@ -241,6 +263,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     }
     if (DIST && i == T - 1) dist[blockIdx.x] = gfinal;
     WT_STAMP(4 + wave);
+    wait_vmcnt0();          // this wave's plane words have left for the L2 (the compiler does not know about them)
     __syncthreads();
     if (wave != 0) return;
     WT_STAMP(8);
@@ -264,8 +287,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
         const int win = max((s >> 5) - 1, 0);
         const int base = 32 * win;
         const int top = bi;
-        const uint2 *rowp = plane + (size_t)max(bi - lane, 0) * pitch + win;
-        const uint2 w0 = rowp[0], w1 = rowp[1];
+        const uint2 *rowp = plane + (size_t)win * rowsP + max(bi - lane, 0);   // lanes read consecutive rows: coalesced
+        const uint2 w0 = rowp[0], w1 = rowp[rowsP];
         const int a0 = (int)w0.x, b0 = (int)w0.y, a1 = (int)w1.x, b1 = (int)w1.y;
         bool more;
         do {   // one row per iteration, no memory access, one taken branch
@@ -307,28 +330,40 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
         int bj = F - 1;
         bi = T - 1;
         int pos = len - 1;
+        int have = -1;        // which (block, row) word pair is cached: the walk stays in a word for up to 32 steps
+        uint32_t ca = 0, cb = 0;
         while (true) {
             if (lane == 0) { pi[pos] = bi; pj[pos] = bj; }
             if (bi == 0 && bj == 0) break;
             if (bi == 0) { --bj; --pos; continue; }
             const int s = bj + (bi & 63);
-            const uint2 AB = plane[(size_t)bi * pitch + (s >> 5)];
+            const int key = (s >> 5) * rowsP + bi;
+            if (key != have) {
+                const uint2 AB = plane[key];
+                ca = __builtin_amdgcn_readfirstlane(AB.x);
+                cb = __builtin_amdgcn_readfirstlane(AB.y);
+                have = key;
+            }
             const int bit = 31 - (s & 31);
-            const uint32_t a = (__builtin_amdgcn_readfirstlane(AB.x) >> bit) & 1u;
-            const uint32_t b = (__builtin_amdgcn_readfirstlane(AB.y) >> bit) & 1u;
+            const uint32_t a = (ca >> bit) & 1u;
+            const uint32_t b = (cb >> bit) & 1u;
             if (b) { --bi; } else if (a) { --bj; } else { --bi; --bj; }
             --pos;
         }
     }
 }
 
-size_t dtw_lds_bytes(int nw, int F) {
-    return (size_t)2 * nw * 64 * dtw_pitch(F) * 4 + (size_t)(nw - 1) * (dtw_bnd_pitch(F) + DUMP) * 8 + 16;
+static size_t dtw_plane_words(int nw, int F) { return (size_t)nw * 64 * dtw_blocks(F); }   // uint2 per unit slot
+
+size_t dtw_lds_bytes(int nw, int F) {   // boundary rows + parking areas + progress words
+    return (size_t)(nw - 1) * (dtw_bnd_pitch(F) + DUMP) * 8 + 16;
 }
+
+int scratch_dtw(hipStream_t st, size_t bytes, void **out);   // the direction planes' arena of (device, stream)
 
 template <bool DIST, bool TINY>
 static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
-                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes, hipStream_t st) {
     static std::once_flag once;  // per instantiation; function attributes are per process on one device
     hipError_t attr_rc = hipSuccess;
     std::call_once(once, [&] {
@@ -339,8 +374,9 @@ static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg,
     for (int nw = 1; nw <= 4; ++nw) {
         if (maxF[nw] == 0) continue;
         const size_t lds = dtw_lds_bytes(nw, maxF[nw]);
+        // (the launches of one call run one after the other on the stream: they share the plane slots)
         hipLaunchKernelGGL((dtw_kernel<DIST, TINY>), dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i,
-                           path_j, path_len, dist);
+                           path_j, path_len, dist, planes, (long long)dtw_plane_words(nw, maxF[nw]));
     }
     WT_HIP(hipGetLastError());
     return WT_OK;
@@ -364,15 +400,19 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
         int *mf = (d.F < 4 || d.T * d.F < 36) ? maxFt : maxF;
         if (d.F > mf[nw]) mf[nw] = d.F;
     }
-    if (dtw_lds_bytes(4, maxF[4] ? maxF[4] : 1) > 160 * 1024) {
-        set_error("wt_dtw_batch: T>192 with F=%d needs more than 160 KiB of LDS", maxF[4]);
-        return WT_E_UNSUPPORTED;
+    size_t slot = 0;   // uint2 words per unit slot: the largest launch class of this call
+    for (int nw = 1; nw <= 4; ++nw) {
+        if (maxF[nw]) slot = std::max(slot, dtw_plane_words(nw, maxF[nw]));
+        if (maxFt[nw]) slot = std::max(slot, dtw_plane_words(nw, maxFt[nw]));
     }
-    int rc = dist ? launch_dtw<true, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, st)
-                  : launch_dtw<false, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, st);
+    uint2 *planes = nullptr;
+    int rc = scratch_dtw(st, (size_t)n_seg * slot * sizeof(uint2), (void **)&planes);
     if (rc) return rc;
-    return dist ? launch_dtw<true, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, st)
-                : launch_dtw<false, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, st);
+    rc = dist ? launch_dtw<true, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st)
+              : launch_dtw<false, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st);
+    if (rc) return rc;
+    return dist ? launch_dtw<true, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
+                : launch_dtw<false, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
 }
 
 }  // namespace wt

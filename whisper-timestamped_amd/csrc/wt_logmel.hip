@@ -19,7 +19,7 @@
 // ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT.  What bounds it
 // (profiles/r2b_logmel_sq_counters.txt): the two instruction streams themselves -- VALU busy 62 % of the kernel
 // (each wave64 VALU instruction of this mix holds its SIMD for 4 cycles), LDS array busy 55 % (a third of it bank
-// conflicts before the [n2][k1] twiddle table and the padded PCM span) -- not the synchronisation: a persistent,
+// conflicts, measured before the [n2][k1] twiddle table) -- not the synchronisation: a persistent,
 // barrier-free, wave-autonomous variant (tools/probes/stft_mel_wave_variant.hip) measured 63 us against 60.
 // Pass 1 writes log10(mel) and one maximum per workgroup (no atomics, nothing
 // to reset); pass 2 reduces them per chunk, applies the clamp/scale and the
@@ -53,7 +53,7 @@ __host__ __device__ constexpr float s20(int m) { return c20(m - 5); }  // sin(x)
         else if (_w == -1.0f) acc -= (x);         \
         else if (_w != 0.0f) acc = fmaf((x), _w, acc); \
     } while (0)
-__constant__ float2 k_w400[400];  // (cos, sin)(2*pi*k/400)
+__constant__ float2 k_w400[400];  // [n2][k1] = (cos, sin)(2*pi*n2*k1/400): the twiddle of stage-2 input n2 for output row k1
 
 constexpr int FPB = 12;             // frames per workgroup
 constexpr int SPAN = 160 * (FPB - 1) + 400;
@@ -139,9 +139,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        float *__restrict__ mel_out) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
-    // The PCM span is stored with every block of 160 samples (one hop) padded to 180 dwords: frames s and s+1 of a wave
-    // then read banks 20 apart instead of the SAME banks (160 = 5 * 32), which made every stage-1 read 2-way conflicted.
-    static_assert(FPB * 204 >= SPAN + ((SPAN - 1) / 160) * 20 + 1, "the padded span must fit in the pw buffer");
+    static_assert(FPB * 204 >= SPAN, "the span must fit in the pw buffer");
     __shared__ float span[FPB * 204];
     __shared__ float2 w400[400];
     __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
@@ -179,20 +177,20 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (i0 >= 0 && i0 + SPAN <= nvs && (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0) {  // block-uniform
         const float4 *src = reinterpret_cast<const float4 *>(x + i0);
         float4 *dst = reinterpret_cast<float4 *>(span);
-        for (int p = tid; p < SPAN / 4; p += 256) dst[p + (p / 40) * 5] = src[p];   // (+20 dwords per 160 samples)
+        for (int p = tid; p < SPAN / 4; p += 256) dst[p] = src[p];
     } else {
         for (int p = tid; p < SPAN; p += 256) {
             int i = i0 + p;
             if (i < 0) i = -i;           // reflect (no edge repeat)
             if (i >= nvs) i = 2 * (nvs - 1) - i;
             i = max(0, min(i, nvs - 1));
-            span[p + (p / 160) * 20] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
+            span[p] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
         }
     }
     for (int p = tid; p < 400; p += 256) hann[p] = k_hann[p];
-    // twiddles laid out [n2][k1]: the 20 lanes of a frame read 20 consecutive float2 (no bank conflict; W400^(n2*k1)
-    // indexed by its exponent put up to 10 lanes on one bank pair) at an immediate offset per n2 (no address arithmetic)
-    for (int p = tid; p < 400; p += 256) w400[p] = k_w400[(p / 20) * (p % 20)];
+    // twiddles laid out [n2][k1] (k_w400 is uploaded in that order): the 20 lanes of a frame read 20 consecutive float2
+    // (W400^(n2*k1) indexed by its exponent put up to 10 lanes on one bank pair) at an immediate offset per n2
+    for (int p = tid; p < 400; p += 256) w400[p] = k_w400[p];
     if (tid < n_mels) { fb_lo[tid] = (unsigned char)g_lo[tid]; fb_n[tid] = (unsigned char)g_n[tid]; fb_off[tid] = (unsigned short)g_off[tid]; }
     if (banded)
         for (int p = tid; p < nnz; p += 256) fbw[p] = g_w[p];
@@ -202,9 +200,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         // ---- stage 1: radix-20 over n1 for this lane's n2 = u (real input, k1 = 0..10) ----
         // Pair n1 with 20-n1 (cos even, sin odd) and k1 with 10-k1 ((-1)^n1 symmetry): 108 MACs instead of 440.
         float a[20];
-        const float *fr = span + slot * 180;
+        const float *fr = span + slot * 160;
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + 20 * (n1 / 8) + u] * hann[20 * n1 + u];
+        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hann[20 * n1 + u];
         float ep[10], em[10];
 #pragma unroll
         for (int n = 1; n < 10; ++n) {
@@ -373,7 +371,8 @@ static int upload_tables(hipStream_t st) {
     const double PI = 3.14159265358979323846;
     for (int n = 0; n < 400; ++n) {
         hann[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / 400.0));
-        w400[n] = make_float2((float)std::cos(2.0 * PI * n / 400.0), (float)std::sin(2.0 * PI * n / 400.0));
+        const int e = (n / 20) * (n % 20);   // n = 20*n2 + k1 -> exponent n2*k1 (<= 361)
+        w400[n] = make_float2((float)std::cos(2.0 * PI * e / 400.0), (float)std::sin(2.0 * PI * e / 400.0));
     }
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_hann), hann, sizeof(hann), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_w400), w400, sizeof(w400), 0, hipMemcpyHostToDevice, st));
