@@ -108,9 +108,13 @@ __device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1
 // once per block.  Unknown to the compiler, the store only makes its counted waits conservative by one (loads return
 // in order among themselves; the store was issued a whole block earlier).  gfx9 reads store data at issue: the
 // registers may be reused at once.  The kernel waits for these stores itself before the backtrack (wait_vmcnt0).
-__device__ __forceinline__ void store_plane_words(const uint2 *base, unsigned voff, uint32_t wa, uint32_t wb) {
+// The address is a per-lane 64-bit VGPR pair, not SGPR base + offset: the hazard recogniser does not look inside an
+// asm statement, and in the register-starved instantiations hipcc reloads a spilled base with v_readlane (a VALU write
+// of an SGPR) right in front of it -- a VMEM instruction that reads that SGPR within 5 wait states sees the old value
+// (measured: memory faults in dtw_kernel<true, true> only).  VGPR operands are interlocked by the hardware.
+__device__ __forceinline__ void store_plane_words(const uint2 *addr, uint32_t wa, uint32_t wb) {
     const uint64_t data = (uint64_t)wa | ((uint64_t)wb << 32);
-    asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"(voff), "v"(data), "s"(base) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(addr), "v"(data) : "memory");
 }
 
 // One 32-step block of the anti-diagonal sweep.
@@ -200,8 +204,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     double *pub = (lane == 63) ? bnd + (size_t)pw * bpitch + 1 : park + (size_t)pw * DUMP + lane;
     const int pubinc = (lane == 63) ? BLK : 0;
     const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
-    unsigned pvoff = 8u * (unsigned)i;                       // byte offset of this lane's word pair in the current block
-    const unsigned pvstep = 8u * (unsigned)rowsP;
+    const uint2 *pword = plane + i;                          // this lane's word pair of the current block
 
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                 }
             }
             sweep_block<EDGE, PUBLISH, DIST, FIRST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-            store_plane_words(plane, pvoff, wa, wb);
-            pvoff += pvstep;
+            store_plane_words(pword, wa, wb);
+            pword += rowsP;
             if (PUBLISH) {
                 pub += pubinc;
                 if (lane == 0) {
