@@ -28,5 +28,20 @@ pw=$(find "$out/pmc_write" -name "*.db" | head -1)
 python $ROOT/tools/rocpd_stats.py "$kt" --skip 2 > "$out/kernel_stats.txt" 2>&1
 python $ROOT/tools/pmc_traffic.py "$pf" "$pw" --workload $wl > "$out/traffic.json" 2> "$out/traffic.err"
 find "$out" -name "*.csv" -size +2M -delete
-find "$out" -name "*.db" -size +20M -delete
+
 tail -1 "$out/bench.json"; head -14 "$out/kernel_stats.txt"; head -30 "$out/e2e_kernel_stats.txt" 2>/dev/null
+# secondary workloads (one line each) and the transcribe()-level traces: plain decoding vs the timestamped data planes
+for w2 in kfull256 kreal largev3_fp16; do
+  timeout 300 python $ROOT/bench.py --workload $w2 --steps 10 --warmup 3 --e2e off --no-cpu-baseline > "$out/bench_$w2.json" 2> "$out/bench_$w2.err" || true
+done
+timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --e2e off --no-cpu-baseline --graph > "$out/bench_graph.json" 2>> "$out/bench.err" || true
+WT_BENCH_FORCE_DIST=1 timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --e2e off --no-cpu-baseline > "$out/bench_force_dist_rccl_1rank.json" 2>> "$out/bench.err" || true
+timeout 300 python $ROOT/tools/bench_transcribe.py base > "$out/timestamp_overhead.json" 2> "$out/timestamp_overhead.err" || true
+timeout 300 python $ROOT/tools/bench_transcribe.py small > "$out/timestamp_overhead_small.json" 2>> "$out/timestamp_overhead.err" || true
+for v in plain timestamped per_segment; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt_tr_$v" -o kt -- python $ROOT/tools/bench_transcribe.py base --only $v > "$out/kt_tr_$v.log" 2>&1
+  kd=$(find "$out/kt_tr_$v" -name "*.db" | head -1)
+  python $ROOT/tools/rocpd_stats.py "$kd" > "$out/transcribe_${v}_kernel_stats.txt" 2>&1
+done
+find "$out" -name "*.db" -delete
+find "$out" -name "*.csv" -delete
