@@ -12,7 +12,7 @@ out=$ROOT/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --workload $wl"
-K="$B --e2e off --no-cpu-baseline"
+K="$B --e2e off --no-cpu-baseline --pipeline 1"   # kernel trace / PMC passes: one batch in flight, stages back to back (what the stage times and the roofline are measured on)
 timeout 600 $B --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- $K --steps 10 --warmup 2 --repeats 5 > "$out/kt.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_fetch.log" 2>&1

@@ -112,21 +112,55 @@ def device_ctx(device):
     return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
 
 
-def pinned(t: torch.Tensor) -> torch.Tensor:
-    """Page-locked copy of a small host tensor (what an asynchronous H2D copy needs)."""
-    return t.pin_memory() if torch.cuda.is_available() else t
+# Page-locked staging buffers are expensive to create (hipHostMalloc: milliseconds) and tiny here (token matrices,
+# padding indices, gather lists): they are pooled per byte-size bucket and handed back after use.
+_PINNED_FREE = {}
+
+
+def _pinned_take(nbytes: int) -> torch.Tensor:
+    bucket = max(256, 1 << (max(int(nbytes), 1) - 1).bit_length())
+    free = _PINNED_FREE.setdefault(bucket, [])
+    return free.pop() if free else torch.empty(bucket, dtype=torch.uint8).pin_memory()
+
+
+def _pinned_give(buf: torch.Tensor):
+    _PINNED_FREE.setdefault(buf.numel(), []).append(buf)
+
+
+class PinnedUpload:
+    """Small host array -> device through pooled page-locked memory, asynchronously.  ``release()`` (after the work
+    that consumed it has been waited for) hands the staging buffer back to the pool."""
+
+    def __init__(self, array, device):
+        src = torch.from_numpy(np.ascontiguousarray(array))
+        self.buf = None
+        if torch.device(device).type == "cuda":
+            nbytes = src.numel() * src.element_size()
+            self.buf = _pinned_take(nbytes)
+            stage = self.buf[:nbytes].view(src.dtype)
+            stage.copy_(src)
+            self.dev = stage.to(device, non_blocking=True)
+        else:
+            self.dev = src
+
+    def release(self):
+        if self.buf is not None:
+            _pinned_give(self.buf)
+            self.buf = None
 
 
 class HostCopy:
     """Asynchronous device->host copy of a small tensor: queued behind the work already on the stream, read with
-    ``wait()``.  (A tensor that already lives on the host is handed back as is.)"""
+    ``wait()`` (pooled page-locked staging; a tensor that already lives on the host is handed back as is)."""
 
     def __init__(self, t: torch.Tensor):
-        self.event = None
+        self.event = self.buf = None
         if t.is_cuda:
-            self.host = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            nbytes = t.numel() * t.element_size()
+            self.buf = _pinned_take(nbytes)
+            self.host = self.buf[:nbytes].view(t.dtype).view(t.shape)
             with torch.cuda.device(t.device):
-                self.host.copy_(t, non_blocking=True)
+                self.host.copy_(t.contiguous(), non_blocking=True)
                 self.event = torch.cuda.Event()
                 self.event.record(torch.cuda.current_stream(t.device))
         else:
@@ -136,6 +170,9 @@ class HostCopy:
         if self.event is not None:
             self.event.synchronize()
             self.event = None
+            self.host = self.host.clone()          # (bytes) -- the staging buffer goes back to the pool
+            _pinned_give(self.buf)
+            self.buf = None
         return self.host
 
 

@@ -220,6 +220,8 @@ _WORKSPACES = {}
 
 def default_workspace(device):
     device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     if device not in _WORKSPACES:
         _WORKSPACES[device] = Workspace(device)
     return _WORKSPACES[device]

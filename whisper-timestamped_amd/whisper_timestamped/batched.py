@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from . import _lib, audio as wt_audio, backend
-from .alignment import AlignmentBatch, Workspace, head_pairs, planned_words, prepare_unit, set_padding
+from .alignment import AlignmentBatch, default_workspace, head_pairs, planned_words, prepare_unit, set_padding
 from .capture import layer_head_slots
 from .confidence import strip_trailing_punctuation
 from .words import AUDIO_SAMPLES_PER_TOKEN, HOP_LENGTH, N_FRAMES
@@ -105,7 +105,7 @@ class BatchedAligner:
         self.ring_dtype, self.mel_dtype = ring_dtype, mel_dtype
         self.fused = efficient.FUSED_ATTENTION if fused_attention is None else fused_attention
         self.n_mels = model.dims.n_mels if hasattr(model.dims, "n_mels") else 80
-        self.workspace = Workspace(self.dev)
+        self.workspace = default_workspace(self.dev)
         self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
         sot = tokenizer.sot_sequence
         if language and len(sot) == 3:                                   # :1230-1232
@@ -127,12 +127,14 @@ class BatchedAligner:
         return [*self.sot_sequence, ts0] + tokens, first, last
 
     def _to_device(self, array, keep):
-        """Small int32 host array -> device through pinned memory, asynchronously (no stream synchronisation)."""
-        host = _lib.pinned(torch.from_numpy(np.ascontiguousarray(array, dtype=np.int32)))
-        keep.append(host)
-        return host.to(self.dev, non_blocking=True)
+        """Small int32 host array -> device through pooled pinned memory, asynchronously (no stream synchronisation)."""
+        up = _lib.PinnedUpload(np.ascontiguousarray(array, dtype=np.int32), self.dev)
+        keep.append(up)
+        return up.dev
 
     def _mark(self, st, name):
+        """Timeline (bench.py): an event pair around every stage's launches -- the pair times the stage's kernels only,
+        not the time the GPU may have waited for the host to queue them."""
         if self.timeline is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(torch.cuda.current_stream(self.dev))
@@ -164,12 +166,13 @@ class BatchedAligner:
                 pcm[b, :n_valid[b]].copy_(job.pcm.reshape(-1), non_blocking=True)
             small = self._to_device(np.concatenate([tok_mat.reshape(-1), n_valid]), st.keep)
             tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
-            self._mark(st, "start")
+            self._mark(st, "logmel<")
             # log-mel of every crop, zero padded to 3000 frames (:1211-1215), and where the padding starts (:1795-1805)
             mel = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES)
             pad_copy = _lib.HostCopy(_lib.find_start_padding(mel))
-            self._mark(st, "logmel")
+            self._mark(st, "logmel>")
             del pcm
+            self._mark(st, "model<")
             # encoder + teacher-forced decoder on the whole batch (:1236-1238); no logit filters on this path (:1245)
             q_out, k_out, captured = [None] * len(self.hooked), [None] * len(self.hooked), [None] * len(self.hooked)
             hooks = []
@@ -187,7 +190,8 @@ class BatchedAligner:
             finally:
                 for h in hooks:
                     h.remove()
-            self._mark(st, "model")
+            self._mark(st, "model>")
+            self._mark(st, "qk_rows<")
             # the alignment heads' QK rows of every window: (B, A, T_max, 1500)
             ring = torch.empty((B, self.n_slots, T_max, self.n_ctx), dtype=self.ring_dtype, device=dev)
             lens = np.array([len(t) for t in fed], dtype=np.int32)
@@ -199,7 +203,7 @@ class BatchedAligner:
                 for l, h, s in zip(self.sel_layer.tolist(), self.sel_head.tolist(), self.sel_slot.tolist()):
                     ring[:, s].copy_(captured[l][:, h])
             del q_out, k_out, captured
-            self._mark(st, "qk_rows")
+            self._mark(st, "qk_rows>")
             # host, while the GPU is busy with the forward pass: tokens -> words, descriptors, which log-probs to read
             n_gather = 0
             gather_rows, gather_toks = [], []
@@ -235,14 +239,16 @@ class BatchedAligner:
                 if u is not None:
                     set_padding(u, None if int(pad_host[b]) < 0 else int(pad_host[b]))
                 batch.add(u)
+            self._mark(st, "align<")
             batch.launch()
-            self._mark(st, "align")
+            self._mark(st, "align>")
+            self._mark(st, "logprob<")
             if n_gather and batch.units:
                 gt = self._to_device(np.concatenate([np.asarray(gather_rows, dtype=np.int32),
                                                       np.asarray(gather_toks, dtype=np.int32)]), st.keep)
                 _lib.logprob_gather_rows(logits.reshape(B * T_max, -1), gt[:n_gather], gt[n_gather:],
                                          out=batch.extra.view(torch.float32))
-            self._mark(st, "logprob")
+            self._mark(st, "logprob>")
             batch.fetch()
             st.batch = batch
             st.keep.extend([ring, logits, tok_dev])
@@ -270,9 +276,15 @@ class BatchedAligner:
                     else:
                         wl.append(torch.empty(0))
             out.append(WindowResult(ws, wl, utoks, first, last, job.tag))
+        for k in st.keep:
+            if isinstance(k, _lib.PinnedUpload):
+                k.release()
         st.keep.clear()
         if self.timeline is not None and st.marks:
-            self.timeline.append({b[0]: a[1].elapsed_time(b[1]) for a, b in zip(st.marks[:-1], st.marks[1:])})
+            ev = dict(st.marks)
+            row = {name[:-1]: ev[name].elapsed_time(ev[name[:-1] + ">"]) for name in ev if name.endswith("<")}
+            row["span"] = st.marks[0][1].elapsed_time(st.marks[-1][1])      # first launch -> last kernel, idle gaps included
+            self.timeline.append(row)
         return out
 
 

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, backend
-from .alignment import AlignmentBatch, Workspace, head_pairs, planned_words, prepare_unit, set_padding
+from .alignment import AlignmentBatch, default_workspace, head_pairs, planned_words, prepare_unit, set_padding
 from .capture import LogitsRing, QKCaptureRing
 from .confidence import segment_confidences
 from .words import HOP_LENGTH, N_AUDIO_CTX, SAMPLE_RATE
@@ -119,7 +119,7 @@ class EfficientSession:
         self._fused_checked = False
         # deferred alignment: units queued during the window, launched when it closes, collected one window later
         self.defer = DEFER_ALIGNMENT and not detect_disfluencies
-        self.workspace = Workspace(dev)
+        self.workspace = default_workspace(dev)    # pinned staging + result buffers survive from call to call
         self.queued = []                 # [(unit, placeholder words, padding handle)] of the window being decoded
         self.in_flight = []              # [(AlignmentBatch, [placeholder word lists])] launched, not yet read
         self._pad_handles = {}           # id(mfcc) -> (mfcc, HostCopy of find_start_padding): queued when the mel appears
