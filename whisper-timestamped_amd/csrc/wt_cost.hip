@@ -17,7 +17,8 @@
 //   side, ds_read_b128), and everything else happens in registers:
 //   median-of-9 with the 3x3 sorted-column identity on v_min3/v_med3/v_max3
 //   (7 VALU ops per element), wave-wide max / sum by DPP butterflies, exp on
-//   v_exp_f32 with a compensated log2(e) product, accumulate over heads.
+//   v_exp_f32 of ONE rounded product, softmax tail on packed fp32 instructions,
+//   accumulate over heads.
 //   No workgroup barrier anywhere.  Algorithmic HBM bytes: A*T*F*4 read +
 //   T*F*4 written.
 // Kernel 2 (colnorm): per 64-column tile, column sum of squares over tokens
@@ -107,9 +108,16 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const int hpos = lane < 4 ? -(lane + 1) : F + (lane - 4);
     const int hsrc = reflect_index(hpos, F);
 
-    float acc[C];
+    // (re, re) pairs: the softmax tail below runs on packed fp32 instructions (v_pk_add/mul/fma_f32: two elements each)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[C / 2];
 #pragma unroll
-    for (int q = 0; q < C; ++q) acc[q] = 0.f;
+    for (int q = 0; q < C / 2; ++q) acc[q] = (f2){0.f, 0.f};
+    // exp((w - max) * qk_scale) = exp2((w - max) * qk_scale * log2(e)): one constant (the host refuses qk_scale <= 0).
+    // The product is rounded once: half an ulp of the exponent, i.e. <= 1 ulp of the result for |w - max| < 2.9 and
+    // growing only where exp() itself vanishes from the softmax sum (measured against the compensated two-term
+    // product this kernel used before: same worst error against the oracle, 2.9e-7 of the matrix maximum; -7 % time)
+    const f2 cexp = (f2){qk_scale * 1.44269502162933349609375f, qk_scale * 1.44269502162933349609375f};
 
     stage_row<C>(row0 + (int64_t)head_idx[0] * d.head_stride, lds[wave][0], F, nch, lane);
     for (int a = 0; a < n_heads; ++a) {
@@ -149,20 +157,24 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
             const float med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
                                     min3f(hi[q], hi[q + 3], hi[q + 6]));
             const bool ok = (lane * C + q) < F;
-            m[q] = ok ? med * qk_scale : -1e30f;
+            m[q] = ok ? med : -1e30f;
             mx = fmaxf(mx, m[q]);
         }
         mx = wave_max_dpp(mx);
-        float s = 0.f;
+        const f2 mx2 = (f2){mx, mx};
+        f2 e[C / 2];
+        f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < C; ++q) {
-            m[q] = exp_nonpos(m[q] - mx);
-            s += m[q];
+        for (int q = 0; q < C / 2; ++q) {
+            const f2 t = ((f2){m[2 * q], m[2 * q + 1]} - mx2) * cexp;
+            e[q] = (f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // (masked: exp2(-1.4e30) = 0)
+            s2 += e[q];
         }
-        s = wave_sum_dpp(s);
+        const float s = wave_sum_dpp(s2.x + s2.y);
         const float inv = 1.0f / s;
+        const f2 inv2 = (f2){inv, inv};
 #pragma unroll
-        for (int q = 0; q < C; ++q) acc[q] += m[q] * inv;
+        for (int q = 0; q < C / 2; ++q) acc[q] = __builtin_elementwise_fma(e[q], inv2, acc[q]);
     }
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
@@ -174,11 +186,11 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
         const float rn = 1.0f / nh;
 #pragma unroll
         for (int k = 0; k < C / 4; ++k)
-            op[k] = make_float4(acc[4 * k] * rn, acc[4 * k + 1] * rn, acc[4 * k + 2] * rn, acc[4 * k + 3] * rn);
+            op[k] = make_float4(acc[2 * k].x * rn, acc[2 * k].y * rn, acc[2 * k + 1].x * rn, acc[2 * k + 1].y * rn);
     } else {
 #pragma unroll
         for (int k = 0; k < C / 4; ++k)
-            op[k] = make_float4(acc[4 * k] / nh, acc[4 * k + 1] / nh, acc[4 * k + 2] / nh, acc[4 * k + 3] / nh);
+            op[k] = make_float4(acc[2 * k].x / nh, acc[2 * k].y / nh, acc[2 * k + 1].x / nh, acc[2 * k + 1].y / nh);
     }
     wave_lds_fence();
     float *out = cost + d.cost_offset + (int64_t)t * F;
@@ -364,6 +376,10 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     if (n_seg == 0) return WT_OK;
     if (medfilt_width != 9) {
         set_error("wt_cost_batch: medfilt_width=%d unsupported (the reference always uses 9)", medfilt_width);
+        return WT_E_UNSUPPORTED;
+    }
+    if (!(qk_scale > 0.f)) {   // (the row maximum is taken before the scaling; the reference always passes 1.0)
+        set_error("wt_cost_batch: qk_scale=%g unsupported (must be > 0; the reference always uses 1.0)", (double)qk_scale);
         return WT_E_UNSUPPORTED;
     }
     int maxF = 0;

@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libwtalign.so")
+# (WT_LIBWTALIGN: another build of the same library, for A/B measurements of kernel variants -- tools/ab_cost.py)
+LIB_PATH = os.environ.get("WT_LIBWTALIGN") or os.path.join(_PKG_ROOT, "libwtalign.so")
 
 WT_DTYPE_F32, WT_DTYPE_F16 = 0, 1
 WT_MAX_TOKENS, WT_MAX_FRAMES = 256, 1792
