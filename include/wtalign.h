@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 2 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows */
+#define WT_ABI_VERSION 2 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern */
 
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
@@ -142,6 +142,17 @@ int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, co
  *   dist     : optional device double[n_seg] = alignment.distance            */
 int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
                  int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
+
+/* wt_dtw_batch with an explicit step pattern:
+ *   WT_STEP_SYMMETRIC1        = dtw.stepPattern.symmetric1 (T.py:1572; what every caller of the reference uses)
+ *   WT_STEP_NO_EMPTY_SUBWORDS = the pattern of T.py:1575-1580 (perform_word_alignment(subwords_can_be_empty=False)):
+ *                               symmetric1 without the previous-token/same-frame move, so that two tokens never share
+ *                               a timestamp; needs T <= F per unit (WT_E_UNSUPPORTED otherwise: dtw-python finds no path) */
+#define WT_STEP_SYMMETRIC1 0
+#define WT_STEP_NO_EMPTY_SUBWORDS 1
+int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                         int step_pattern, int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist,
+                         void *stream);
 
 /* wt_cost_batch followed by wt_dtw_batch on the same stream. */
 int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,

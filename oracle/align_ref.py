@@ -367,10 +367,10 @@ def perform_word_alignment_ref(tokens, attention_weights, tokenizer, use_space=T
                                refine_whisper_precision_nframes=0, remove_punctuation_from_words=False,
                                include_punctuation_in_timing=False, unfinished_decoding=False,
                                alignment_heads=None, medfilt_width=9, qk_scale=1.0,
-                               detect_disfluencies=True, return_internals=False):
+                               detect_disfluencies=True, return_internals=False, subwords_can_be_empty=True):
     """Same contract as the reference function.  ``alignment_heads`` is None
-    or an (n,2) array of (layer, head).  ``subwords_can_be_empty=False`` is not
-    restated (no caller passes it)."""
+    or an (n,2) array of (layer, head).  ``subwords_can_be_empty=False`` selects
+    the step pattern of transcribe.py:1575-1580 (no caller of the reference passes it)."""
     tokens = list(tokens)
     win = frame_window_ref(tokens, tokenizer.timestamp_begin, refine_whisper_precision_nframes)
     if win is None:
@@ -404,7 +404,7 @@ def perform_word_alignment_ref(tokens, attention_weights, tokenizer, use_space=T
 
     sel = select_heads_ref(attention_weights, start_token, end_token, alignment_heads)
     cost = cost_matrix_ref(sel, medfilt_width, qk_scale, max_duration_ref(mfcc), start_token)
-    ali = dtw_ref(cost)                                                               # :1581
+    ali = dtw_ref(cost, step_pattern=0 if subwords_can_be_empty else 1)               # :1571-1581
     jumps = jumps_from_path(ali.index1s, ali.index2s)                                 # :1648-1652
 
     jumps_start = jumps

@@ -61,7 +61,7 @@ def install(monkeypatch):
             sel = u.qk[:, :, u.start_token:u.end_token].contiguous().float().numpy()
             pad = u.pad_from if u.pad_from >= 0 else None
             cost = O.cost_matrix_ref(sel, self.medfilt_width, self.qk_scale, pad, u.start_token)
-            r = O.dtw_ref(cost)
+            r = O.dtw_ref(cost, step_pattern=self.step_pattern)
             jumps = O.jumps_from_path(r.index1s, r.index2s).astype(np.int64)
             self._numbers.append((jumps, O.jumps_start_ref(cost, jumps) if u.detect_disfluencies else None))
         return self

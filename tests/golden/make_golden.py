@@ -65,12 +65,17 @@ def load_reference():
     d = types.ModuleType("dtw")
     sp = types.ModuleType("dtw.stepPattern")
     sp.symmetric1 = "symmetric1"
+    # the pattern the reference builds itself for subwords_can_be_empty=False (transcribe.py:1575-1580): rows of
+    # (pattern number, token step, frame step, weight) -- recognised here by its rows
+    sp._c = lambda *rows: tuple(rows)
+    sp.StepPattern = lambda rows: ("custom",) + tuple(rows)
     d.stepPattern = sp
+    NO_EMPTY = ("custom", 1, 1, 1, -1, 1, 0, 0, 1, 2, 0, 1, -1, 2, 0, 0, 1)
 
     def dtw_stub(x, step_pattern=None, **kw):
-        assert step_pattern == "symmetric1"
+        assert step_pattern in ("symmetric1", NO_EMPTY), step_pattern
         _captured["cost"] = np.array(x, dtype=np.float64, copy=True)
-        res = O.dtw_ref(x)
+        res = O.dtw_ref(x, step_pattern=0 if step_pattern == "symmetric1" else 1)
         _captured["index1s"], _captured["index2s"] = res.index1s, res.index2s
         return res
 
@@ -124,6 +129,11 @@ def align_case_list():
     C.append(dict(name="tiny_F_small", seed=115, L=4, H=6, heads=TINY_HEADS, n_text=1, start=10, end=12, refine=0))
     C.append(dict(name="base_rmpunct", seed=116, L=6, H=8, heads=BASE_HEADS, n_text=18, start=20, end=380, refine=25,
                   remove_punct=True))
+    # subwords_can_be_empty=False: the reference's own second step pattern (transcribe.py:1575-1580)
+    C.append(dict(name="base_noempty", seed=117, L=6, H=8, heads=BASE_HEADS, n_text=15, start=120, end=420, refine=25,
+                  noempty=True))
+    C.append(dict(name="tiny_noempty_tight", seed=118, L=4, H=6, heads=TINY_HEADS, n_text=22, start=700, end=726, refine=0,
+                  noempty=True))    # 24 tokens on 26 frames: almost every token gets exactly one frame
     return C
 
 
@@ -166,6 +176,7 @@ def main():
             remove_punctuation_from_words=c.get("remove_punct", False),
             alignment_heads=ah,
             detect_disfluencies=c.get("disfl", False),
+            subwords_can_be_empty=not c.get("noempty", False),
         )
         rec = dict(c)
         rec["words"] = [dict(text=w["text"], start=w["start"], end=w["end"], tokens=w["tokens"],

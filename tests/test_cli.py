@@ -1,0 +1,81 @@
+"""The command line (whisper_timestamped/cli.py): the reference's options and output files
+(/root/reference/whisper_timestamped/transcribe.py:2964-3182).  No trained checkpoint exists offline, so load_model is
+pointed at a random-weight tiny model; kernels = the CPU oracle (tests/cpu_kernel_standin.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import schema_check
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _wav(path, seconds=2.5, seed=0):
+    from scipy.io import wavfile
+    rng = np.random.RandomState(seed)
+    t = np.arange(int(seconds * 16000)) / 16000.0
+    x = 0.05 * rng.standard_normal(t.shape) + 0.1 * np.sin(2 * np.pi * 220.0 * t)
+    wavfile.write(path, 16000, (x * 32767).astype(np.int16))
+
+
+def _patch(monkeypatch):
+    import cpu_kernel_standin
+    import whisper_double as W
+    W.install()
+    cpu_kernel_standin.install(monkeypatch)
+    from whisper_timestamped import cli as C
+    monkeypatch.setattr(C, "load_model", lambda name, device=None, download_root=None, backend=None:
+                        W.build_model("tiny" if name in ("tiny", "small") else name, seed=0, device="cpu"))
+    return C
+
+
+def test_cli_writes_every_output_format(tmp_path, monkeypatch):
+    C = _patch(monkeypatch)
+    wav = tmp_path / "clip.wav"
+    _wav(str(wav))
+    out = tmp_path / "out"
+    C.cli([str(wav), "--model", "tiny", "--device", "cpu", "--language", "en", "--output_dir", str(out), "--fp16", "False",
+           "--punctuations_with_words", "False", "--accurate", "--efficient"])
+    names = sorted(os.listdir(out))
+    assert names == sorted("clip.wav" + s for s in (".words.json", ".txt", ".vtt", ".words.vtt", ".srt", ".words.srt", ".csv",
+                                                    ".words.csv", ".tsv", ".words.tsv"))
+    result = json.load(open(out / "clip.wav.words.json", encoding="utf-8"))
+    schema_check.validate(result, json.load(open(os.path.join(HERE, "golden", "json_schema.json"))))
+    n_words = sum(len(s["words"]) for s in result["segments"])
+    assert (out / "clip.wav.vtt").read_text().startswith("WEBVTT\n")
+    assert (out / "clip.wav.words.srt").read_text().count(" --> ") == n_words
+    assert len((out / "clip.wav.words.csv").read_text().strip().splitlines()) == n_words
+    assert (out / "clip.wav.tsv").read_text().splitlines()[0].split("\t") == ["start", "end", "text"]
+
+
+def test_cli_prints_filtered_json_without_output_dir(tmp_path, monkeypatch, capsys):
+    C = _patch(monkeypatch)
+    wav = tmp_path / "clip.wav"
+    _wav(str(wav), seconds=1.5, seed=1)
+    C.cli([str(wav), "--model", "tiny", "--device", "cpu", "--language", "en", "--fp16", "False", "--output_format", "json,srt",
+           "--naive", "--recompute_all_timestamps", "True"])
+    shown = json.loads(capsys.readouterr().out)
+    assert set(shown) <= {"text", "segments", "language", "language_probs", "speech_activity"}
+    for seg in shown["segments"]:
+        assert set(seg) <= {"text", "start", "end", "confidence", "words"}
+
+
+def test_cli_options_are_the_reference_ones():
+    """Option names and defaults of the reference's parser (transcribe.py:3000-3079)."""
+    import whisper_double as W
+    W.install()
+    from whisper_timestamped import cli as C
+    p = C.build_parser()
+    d = {a.dest: a.default for a in p._actions}
+    want = dict(model="small", model_dir=None, backend="openai-whisper", output_dir=None, output_format="all", task="transcribe",
+                language=None, vad=False, detect_disfluencies=False, recompute_all_timestamps=False, punctuations_with_words=True,
+                temperature=0.0, best_of=None, beam_size=None, patience=None, length_penalty=None, suppress_tokens="-1",
+                initial_prompt=None, condition_on_previous_text=True, fp16=None, temperature_increment_on_fallback=0.0,
+                compression_ratio_threshold=2.4, logprob_threshold=-1.0, no_speech_threshold=0.6, threads=0,
+                compute_confidence=True, verbose=False, plot=False, debug=False, naive=False)
+    for k, v in want.items():
+        assert d[k] == v, (k, d[k], v)
+    with pytest.raises(ValueError):
+        C._output_formats("json,doc")

@@ -139,6 +139,50 @@ def test_dtw_rejects_unsupported():
         L.dtw_batch(t, descs, L.descs_to_device(descs, DEV), torch.zeros(257, dtype=torch.int32, device=DEV))
 
 
+def test_dtw_no_empty_subwords_pattern_bit_exact():
+    """transcribe.py:1575-1580 (perform_word_alignment(subwords_can_be_empty=False)): symmetric1 without the previous-
+    token/same-frame move -- against the oracle's restatement of dtw-python with that pattern; every token then owns at
+    least one frame (strictly increasing jumps); T > F is refused like dtw-python's "no warping path"."""
+    L = _lib()
+    rng = np.random.RandomState(41)
+    shapes = [(1, 1), (1, 9), (2, 2), (5, 5), (7, 100), (64, 64), (65, 300), (130, 131), (224, 1500), (256, 1792), (33, 40)]
+    costs = [(-rng.rand(T, F)).astype(np.float32) for T, F in shapes]
+    costs += [np.zeros((12, 40), np.float32), -(rng.randint(0, 3, size=(90, 400)) / 2.0).astype(np.float32)]
+    descs = L.make_descs(len(costs))
+    for d, c in zip(descs, costs):
+        d["T"], d["F"] = c.shape
+        d["pad_from"] = -1
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    flat = np.zeros(n_cost, dtype=np.float32)
+    for d, c in zip(descs, costs):
+        flat[d["cost_offset"]:d["cost_offset"] + c.size] = c.ravel()
+    jumps = torch.full((n_jumps,), -7, dtype=torch.int32, device=DEV)
+    pi = torch.full((n_path,), -7, dtype=torch.int32, device=DEV)
+    pj = torch.full((n_path,), -7, dtype=torch.int32, device=DEV)
+    pl = torch.zeros(len(costs), dtype=torch.int32, device=DEV)
+    dist = torch.zeros(len(costs), dtype=torch.float64, device=DEV)
+    L.dtw_batch(torch.from_numpy(flat).to(DEV), descs, L.descs_to_device(descs, DEV), jumps, pi, pj, pl, dist,
+                step_pattern=L.WT_STEP_NO_EMPTY_SUBWORDS)
+    torch.cuda.synchronize()
+    j, pi, pj, pl, dist = jumps.cpu().numpy(), pi.cpu().numpy(), pj.cpu().numpy(), pl.cpu().numpy(), dist.cpu().numpy()
+    for k, (d, c) in enumerate(zip(descs, costs)):
+        T, F = c.shape
+        r = O.dtw_ref(c.astype(np.float64), step_pattern=1)
+        n = int(pl[k])
+        assert n == len(r.index1s) == F
+        assert np.array_equal(pi[d["path_offset"]:d["path_offset"] + n], r.index1s), c.shape
+        assert np.array_equal(pj[d["path_offset"]:d["path_offset"] + n], r.index2s), c.shape
+        jm = j[d["jumps_offset"]:d["jumps_offset"] + T + 1]
+        assert np.array_equal(jm, O.jumps_from_path(r.index1s, r.index2s)) and (np.diff(jm[:-1]) > 0).all()
+        assert dist[k] == r.distance
+    descs = L.make_descs(1)
+    descs[0]["T"], descs[0]["F"] = 9, 8
+    L.layout_outputs(descs)
+    with pytest.raises(L.WtError, match="no warping path"):
+        L.dtw_batch(torch.zeros(9 * 8 + 4, device=DEV), descs, L.descs_to_device(descs, DEV),
+                    torch.zeros(10, dtype=torch.int32, device=DEV), step_pattern=L.WT_STEP_NO_EMPTY_SUBWORDS)
+
+
 def test_dtw_largest_shape_is_supported():
     """T = 256 with F = 1792: refused in round 1 (direction planes in LDS: > 160 KiB); the planes live in the scratch
     arena now, so the whole (WT_MAX_TOKENS, WT_MAX_FRAMES) range runs -- several units per launch class."""
@@ -227,7 +271,7 @@ def test_perform_word_alignment_matches_reference_fixture(case):
         tokens, [a.to(DEV) for a in att], tok, use_space=case.get("use_space", True),
         mfcc=None if mfcc is None else mfcc.to(DEV), refine_whisper_precision_nframes=case["refine"],
         remove_punctuation_from_words=case.get("remove_punct", False), alignment_heads=ah,
-        detect_disfluencies=case.get("disfl", False))
+        detect_disfluencies=case.get("disfl", False), subwords_can_be_empty=not case.get("noempty", False))
     exp = case["words"]
     assert [w["text"] for w in words] == [w["text"] for w in exp]
     assert [w["tokens"] for w in words] == [w["tokens"] for w in exp]

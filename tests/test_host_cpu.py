@@ -188,6 +188,11 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 9, 1.0, p, 0) == -3 and b"unsupported shape" in L.wt_last_error()
     assert L.wt_dtw_batch(p, p, p, 1, p, 0, 0, 0, 0, 0) == -3 and b"unsupported shape" in L.wt_last_error()
     assert L.wt_dtw_batch(p, p, p, 1, p, p, 0, 0, 0, 0) == -1                          # path_i without path_j
+    descs[0]["T"], descs[0]["F"] = 10, 100
+    assert L.wt_dtw_batch_pattern(p, p, p, 1, 7, p, 0, 0, 0, 0, 0) == -1 and b"step_pattern=7" in L.wt_last_error()
+    descs[0]["T"], descs[0]["F"] = 30, 20                                              # more tokens than frames
+    assert L.wt_dtw_batch_pattern(p, p, p, 1, 1, p, 0, 0, 0, 0, 0) == -3 and b"no warping path" in L.wt_last_error()
+    descs[0]["F"] = 5000
     assert L.wt_logprob_gather_batch(p, 0, 10, 4, 100, p, p, 0, p, 0) == -1            # row_stride < V
     assert L.wt_logprob_gather_batch(p, 0, 100, 4, 100, p, p, 2, p, 0) == -1           # suppress_rows not in {0,1,n}
     assert L.wt_logprob_gather_batch(p, 0, 100, 0, 100, p, 0, 0, p, 0) == 0

@@ -25,7 +25,8 @@ def test_oracle_alignment_matches_reference_fixture(case):
         refine_whisper_precision_nframes=case["refine"],
         remove_punctuation_from_words=case.get("remove_punct", False),
         alignment_heads=None if heads is None else np.array(heads),
-        detect_disfluencies=case.get("disfl", False), return_internals=True)
+        detect_disfluencies=case.get("disfl", False), return_internals=True,
+        subwords_can_be_empty=not case.get("noempty", False))
     # the f64 cost built by the reference's own lines 1540-1568 (captured at the dtw call)
     ref_cost = COSTS[case["name"]].astype(np.float64)
     assert internals["cost"].shape == tuple(case["cost_shape"])

@@ -79,7 +79,7 @@ void scratch_forget_tags() {
 
 int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, int, float, float *,
                hipStream_t);
-int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int32_t *, int32_t *, int32_t *, int32_t *,
+int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int, int32_t *, int32_t *, int32_t *, int32_t *,
               double *, hipStream_t);
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
                          hipStream_t);
@@ -138,7 +138,15 @@ int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, co
 
 int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
                  int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream) {
-    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, jumps, path_i, path_j, path_len, dist, (hipStream_t)stream);
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist,
+                         (hipStream_t)stream);
+}
+
+int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                         int step_pattern, int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist,
+                         void *stream) {
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, step_pattern, jumps, path_i, path_j, path_len, dist,
+                         (hipStream_t)stream);
 }
 
 int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
@@ -147,7 +155,8 @@ int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, c
     int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost,
                             (hipStream_t)stream);
     if (rc) return rc;
-    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, jumps, path_i, path_j, path_len, dist, (hipStream_t)stream);
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist,
+                         (hipStream_t)stream);
 }
 
 int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps, int32_t *jumps_start,

@@ -128,7 +128,10 @@ __device__ __forceinline__ void store_plane_words(const uint2 *addr, uint32_t wa
 // FIRST: the block that holds step 0 on the first wave.  Cell (0,0) is seeded through lane 0's `diag` (u1 = 0.0, so
 // that p1 = 0 + lm[0,0] = cm[0,0] as in computeCM); wave_shr:1 never overwrites lane 0, so that seed must be
 // retired to +inf before u1 comes back as "g[-1, 1]" at step 1 -- two moves, once per unit, none in the steady loop.
-template <bool EDGE, bool PUBLISH, bool DIST, bool FIRST = false>
+// NOUP: the reference's other step pattern (T.py:1575-1580, subwords_can_be_empty=False): "symmetric1 without the
+// possibility to have the same timestamp for two tokens" = candidates p1 (diagonal) and p2 (same token, previous frame)
+// only; the previous-token/same-frame candidate never exists, so its plane bit is never set.
+template <bool EDGE, bool PUBLISH, bool DIST, bool FIRST = false, bool NOUP = false>
 __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1,
                                             const double (&edge)[BLK], uint32_t &wa, uint32_t &wb, double *pub, int s0,
                                             int sfinal, double &gfinal) {
@@ -142,7 +145,7 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
         const double c = (double)cur[k];
         const double p1 = diag + c;
         const double p2 = g + c;
-        const double p3 = up + c;
+        const double p3 = NOUP ? __builtin_inf() : up + c;
         const double m12 = __builtin_fmin(p1, p2);
         const double best = __builtin_fmin(m12, p3);
         // plane A: "same token, previous frame" beats the diagonal; plane B: "previous token, same frame" beats both
@@ -153,7 +156,7 @@ __device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, 
     }
 }
 
-template <bool DIST, bool TINY>
+template <bool DIST, bool TINY, bool NOUP>
 __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
                            int32_t *__restrict__ path_i, int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
                            double *__restrict__ dist, uint2 *planes, long long plane_stride) {
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                     edge[2 * k + 1] = v.y;
                 }
             }
-            sweep_block<EDGE, PUBLISH, DIST, FIRST>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
+            sweep_block<EDGE, PUBLISH, DIST, FIRST, NOUP>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
             store_plane_words(pword, wa, wb);
             pword += rowsP;
             if (PUBLISH) {
@@ -364,13 +367,13 @@ size_t dtw_lds_bytes(int nw, int F) {   // boundary rows + parking areas + progr
 
 int scratch_dtw(hipStream_t st, size_t bytes, void **out);   // the direction planes' arena of (device, stream)
 
-template <bool DIST, bool TINY>
+template <bool DIST, bool TINY, bool NOUP>
 static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes, hipStream_t st) {
     static std::once_flag once;  // per instantiation; function attributes are per process on one device
     hipError_t attr_rc = hipSuccess;
     std::call_once(once, [&] {
-        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY>),
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY, NOUP>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     WT_HIP(attr_rc);
@@ -378,17 +381,32 @@ static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg,
         if (maxF[nw] == 0) continue;
         const size_t lds = dtw_lds_bytes(nw, maxF[nw]);
         // (the launches of one call run one after the other on the stream: they share the plane slots)
-        hipLaunchKernelGGL((dtw_kernel<DIST, TINY>), dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i,
+        hipLaunchKernelGGL((dtw_kernel<DIST, TINY, NOUP>), dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i,
                            path_j, path_len, dist, planes, (long long)dtw_plane_words(nw, maxF[nw]));
     }
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
 
-int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
-              int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+template <bool NOUP>
+static int launch_all(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, const int *maxFt,
+                      int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes,
+                      hipStream_t st) {
+    int rc = dist ? launch_dtw<true, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st)
+                  : launch_dtw<false, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st);
+    if (rc) return rc;
+    return dist ? launch_dtw<true, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
+                : launch_dtw<false, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
+}
+
+int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int step_pattern,
+              int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
     if (!cost || !segs_host || !segs_dev || !jumps || n_seg < 0 || (!path_i != !path_j)) {
         set_error("wt_dtw_batch: null pointer or bad count");
+        return WT_E_BADARG;
+    }
+    if (step_pattern != WT_STEP_SYMMETRIC1 && step_pattern != WT_STEP_NO_EMPTY_SUBWORDS) {
+        set_error("wt_dtw_batch: step_pattern=%d", step_pattern);
         return WT_E_BADARG;
     }
     if (n_seg == 0) return WT_OK;
@@ -402,6 +420,10 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
         const int nw = (d.T + 63) / 64;
         int *mf = (d.F < 4 || d.T * d.F < 36) ? maxFt : maxF;
         if (d.F > mf[nw]) mf[nw] = d.F;
+        if (step_pattern == WT_STEP_NO_EMPTY_SUBWORDS && d.T > d.F) {   // every token takes a frame: dtw-python finds no path
+            set_error("wt_dtw_batch: unit %d has T=%d > F=%d: no warping path without same-frame token moves", s, d.T, d.F);
+            return WT_E_UNSUPPORTED;
+        }
     }
     size_t slot = 0;   // uint2 words per unit slot: the largest launch class of this call
     for (int nw = 1; nw <= 4; ++nw) {
@@ -411,11 +433,9 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
     uint2 *planes = nullptr;
     int rc = scratch_dtw(st, (size_t)n_seg * slot * sizeof(uint2), (void **)&planes);
     if (rc) return rc;
-    rc = dist ? launch_dtw<true, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st)
-              : launch_dtw<false, false>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st);
-    if (rc) return rc;
-    return dist ? launch_dtw<true, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
-                : launch_dtw<false, true>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
+    return step_pattern == WT_STEP_SYMMETRIC1
+               ? launch_all<false>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
+               : launch_all<true>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
 }
 
 }  // namespace wt

@@ -29,7 +29,8 @@ assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
-           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows"]
+           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern"]
+WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
 ABI_VERSION = 2
 
 
@@ -65,6 +66,7 @@ def load():
     L.wt_qk_rows_batch.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, f32, vp, vp, vp, i32, vp, vp, vp, i32, i64,
                                    i64, i64, vp]
     L.wt_logprob_gather_rows.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp]
+    L.wt_dtw_batch_pattern.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     if L.wt_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} exports ABI version {L.wt_version()}, this package needs {ABI_VERSION}: rebuild it "
                           f"(`make -C {_PKG_ROOT}/csrc`)")
@@ -236,12 +238,12 @@ def cost_batch(qk: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, hea
 
 
 def dtw_batch(cost: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, jumps: torch.Tensor, path_i=None, path_j=None,
-              path_len=None, dist=None):
+              path_len=None, dist=None, step_pattern: int = WT_STEP_SYMMETRIC1):
     _need_cuda(cost, "cost")
     same_device(cost, descs_dev, jumps, path_i, path_j, path_len, dist)
     with on_device(cost) as st:
-        rc = load().wt_dtw_batch(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), len(descs), jumps.data_ptr(),
-                                 _ptr(path_i), _ptr(path_j), _ptr(path_len), _ptr(dist), st)
+        rc = load().wt_dtw_batch_pattern(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), len(descs), int(step_pattern),
+                                         jumps.data_ptr(), _ptr(path_i), _ptr(path_j), _ptr(path_len), _ptr(dist), st)
     _check(rc, "wt_dtw_batch")
 
 

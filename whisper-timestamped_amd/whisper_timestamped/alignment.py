@@ -235,9 +235,12 @@ class AlignmentBatch:
     for values of its own (the batched naive strategy puts its chosen-token log-probabilities there) so that one
     copy brings everything to the host."""
 
-    def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False, workspace=None, extra_words=0):
+    def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False, workspace=None, extra_words=0,
+                 subwords_can_be_empty=True):
         self.units: list[AlignmentUnit] = []
         self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
+        # transcribe.py:1571-1580: symmetric1, or the pattern without the previous-token/same-frame move
+        self.step_pattern = _lib.WT_STEP_SYMMETRIC1 if subwords_can_be_empty else _lib.WT_STEP_NO_EMPTY_SUBWORDS
         self.keep_cost, self.want_path = keep_cost, want_path
         self.cost = self.jumps = self.descs = None
         self.path_i = self.path_j = self.path_len = self.dist = None
@@ -299,11 +302,21 @@ class AlignmentBatch:
                 self.path_len = torch.empty(n_units, dtype=torch.int32, device=dev)
                 self.dist = torch.empty(n_units, dtype=torch.float64, device=dev)
             L = _lib.load()
-            rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
-                                  n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
-                                  cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
-                                  _lib._ptr(self.path_len), _lib._ptr(self.dist), stream)
-            _lib._check(rc, "wt_align_batch")
+            if self.step_pattern == _lib.WT_STEP_SYMMETRIC1:
+                rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
+                                      n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
+                                      cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
+                                      _lib._ptr(self.path_len), _lib._ptr(self.dist), stream)
+                _lib._check(rc, "wt_align_batch")
+            else:
+                rc = L.wt_cost_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
+                                     n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
+                                     cost.data_ptr(), stream)
+                _lib._check(rc, "wt_cost_batch")
+                rc = L.wt_dtw_batch_pattern(cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), n_units,
+                                            self.step_pattern, jumps.data_ptr(), _lib._ptr(self.path_i),
+                                            _lib._ptr(self.path_j), _lib._ptr(self.path_len), _lib._ptr(self.dist), stream)
+                _lib._check(rc, "wt_dtw_batch_pattern")
             if disfl:                                          # token starts moved to their last attention peak
                 rc = L.wt_disfluency_batch(cost.data_ptr(), descs_dev.data_ptr(), n_units, jumps.data_ptr(),
                                            slot.result[n_jumps:2 * n_jumps].data_ptr(), DISFLUENCY_MIN_PROMINENCE,
@@ -420,8 +433,6 @@ def perform_word_alignment(tokens, attention_weights, tokenizer, use_space=True,
                            plot=False, debug=False):
     """Drop-in for the reference function (same arguments, same list of
     dict(text, start, end, tokens, tokens_indices)); the numerics run on the GPU."""
-    if not subwords_can_be_empty:
-        raise NotImplementedError("subwords_can_be_empty=False (no caller of the reference passes it)")
     if plot:
         raise NotImplementedError("plot_word_alignment: debug plotting is out of scope (SURVEY.md section 2, row 17)")
     unit = prepare_unit(tokens, attention_weights, tokenizer, use_space=use_space, mfcc=mfcc,
@@ -434,6 +445,6 @@ def perform_word_alignment(tokens, attention_weights, tokenizer, use_space=True,
         if debug:
             logger.debug(f"Got empty segment in {tokenizer.decode_with_timestamps(list(tokens))}")
         return []
-    batch = AlignmentBatch(medfilt_width=medfilt_width, qk_scale=qk_scale)
+    batch = AlignmentBatch(medfilt_width=medfilt_width, qk_scale=qk_scale, subwords_can_be_empty=subwords_can_be_empty)
     batch.add(unit)
     return batch.run()[0]
