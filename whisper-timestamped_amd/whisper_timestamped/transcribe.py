@@ -126,7 +126,13 @@ def transcribe_timestamped(
 
     Arguments, defaults and the returned dictionary are those of the reference
     (whisper's result + per-segment ``confidence`` and ``words[{text,start,end,confidence}]``,
-    optional ``language_probs``).  ``model`` must live on the GPU."""
+    optional ``language_probs``).  ``model`` must live on the GPU.
+
+    Accepted by the signature but NOT supported here (the call raises ``NotImplementedError``):
+    ``vad=True / "silero" / "auditok"`` (the detectors are third-party models that need network access -- pass the
+    speech islands as ``vad=[(start, end), ...]``, which runs the reference's glue / back-conversion),
+    ``plot_word_alignment`` (debug plots), and a HuggingFace ``transformers`` model object as ``model``.
+    Module switches that trade exact reference arithmetic for speed are listed in INTEGRATION.md ("Switches")."""
     if seed is not None:
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
