@@ -503,8 +503,15 @@ def run_e2e(dev, args, rank, world, dist):
     for m in model.modules():
         if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
             m.half()
-    _, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
+    res16, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
     out["fp16_model"] = fp16
+    # ... and with the forward pass replayed as ONE captured HIP graph (the eager half-precision pass is bound by the
+    # Python dispatch of ~300 small launches, not by the GPU)
+    res_g, fp16g = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, forward_graph=True, **opts), "fp16 graph")
+    fp16g["words_equal_the_eager_pass"] = all([w["text"] for w in a.words] == [w["text"] for w in b.words] and
+                                              all(abs(x["start"] - y["start"]) <= 0.02 and abs(x["end"] - y["end"]) <= 0.02
+                                                  for x, y in zip(a.words, b.words)) for a, b in zip(res_g, res16))
+    out["fp16_model_forward_as_hip_graph"] = fp16g
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same chunks through the reference-shaped CPU path, bounded sample

@@ -126,3 +126,17 @@ def test_segment_by_segment_alignment_gives_the_same_result(monkeypatch):
         case = next(c for c in CASES if c["name"] == name)
         got = run_case(copy.deepcopy(case))
         compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+
+
+def test_naive_strategy_prints_words_when_verbose(monkeypatch, capsys):
+    """The reference prints every word inside the naive loop when verbose is truthy (transcribe.py:1304-1305) -- with the
+    window-by-window second pass and with the batched one."""
+    import re
+    cpu_kernel_standin.install(monkeypatch)
+    for name in ("naive_greedy", "naive_no_trust_three_windows"):
+        case = copy.deepcopy(next(c for c in CASES if c["name"] == name))
+        case["opts"]["verbose"] = True
+        got = run_case(case)
+        shown = [l for l in capsys.readouterr().out.splitlines() if re.match(r"^\[\d\d:\d\d\.\d{3} --> \d\d:\d\d\.\d{3}\] ", l)]
+        n_words = sum(len(s["words"]) for s in got["segments"])
+        assert n_words > 0 and len([l for l in shown if not l.endswith("] ")]) >= n_words
