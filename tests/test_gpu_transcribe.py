@@ -212,6 +212,38 @@ def test_batched_forward_as_hip_graph_equals_eager():
             assert np.allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,heads", [("small", "table"), ("tiny-v3", None)])
+def test_batched_aligner_whole_batch_equals_one_window_at_a_time(name, heads):
+    """Other model shapes through the batched kernels: whisper-small dims (12 heads of 64, the 10 table heads spread over
+    layers 5..10) and a 128-mel / all-heads-of-the-top-layers configuration -- five windows in one launch set against the
+    same windows one at a time (the indexing of wt_qk_rows_batch / wt_logprob_gather_rows is what differs)."""
+    import numpy as np
+    import whisper_double as W
+    W.install()
+    from whisper_timestamped.batched import BatchedAligner, WindowJob, align_windows
+    from whisper_timestamped.transcribe import get_alignment_heads
+    model = W.build_model(name, seed=1, device="cuda:0")
+    if hasattr(model, "alignment_heads"):
+        del model.alignment_heads
+    ah = get_alignment_heads(model) if heads == "table" else None
+    tk = W.tokenizer.get_tokenizer(True, num_languages=model.num_languages, language="en", task="transcribe")
+    g = torch.Generator().manual_seed(11)
+    ts0 = tk.timestamp_begin
+    jobs = []
+    for k in range(5):
+        pcm = (torch.randn(int((12 + 4 * k) * 16000), generator=g) * 0.1).to("cuda:0")
+        toks = [ts0 + 3] + G.text_ids(400 + k, 5 + 3 * k) + [ts0 + 300, ts0 + 310] + G.text_ids(500 + k, 4) + [ts0 + 550]
+        jobs.append(WindowJob(pcm, toks, pcm.numel(), tag=k))
+    kw = dict(language="en", alignment_heads=ah, word_alignment_most_top_layers=None if heads == "table" else 3)
+    whole = list(align_windows(BatchedAligner(model, tk, **kw), jobs, 5))
+    single = list(align_windows(BatchedAligner(model, tk, **kw), jobs, 1))
+    for a, b in zip(whole, single):
+        assert [w["text"] for w in a.words] == [w["text"] for w in b.words] and len(a.words) > 0
+        assert max([0.0] + [max(abs(x["start"] - y["start"]), abs(x["end"] - y["end"])) for x, y in zip(a.words, b.words)]) <= 0.02
+        for x, y in zip(a.word_logprobs, b.word_logprobs):
+            assert np.allclose(x.numpy(), y.numpy(), rtol=0, atol=2e-4)
+
+
 def test_transcribe_aligning_segment_by_segment(monkeypatch):
     """efficient.DEFER_ALIGNMENT = False: a synchronous alignment per flushed segment, as the reference does."""
     from whisper_timestamped import efficient
