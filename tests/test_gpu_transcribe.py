@@ -255,6 +255,23 @@ def test_transcribe_aligning_segment_by_segment(monkeypatch):
         _report(name + "[segment by segment]", dt, dc)
 
 
+def test_front_end_self_check(monkeypatch):
+    """backend.gpu_log_mel: the HIP front end replaces the backend's log_mel_spectrogram only after reproducing it on a
+    probe; a backend with another front end (here: another normalisation) keeps its own."""
+    import sys
+    import whisper_double as W
+    W.install()
+    from whisper_timestamped import backend
+    mod = sys.modules["whisper.transcribe"]
+    backend._FRONT_END_OK.clear()
+    with backend.gpu_log_mel("cuda:0", enabled=True) as on:
+        assert on is True
+    other = mod.log_mel_spectrogram
+    monkeypatch.setattr(mod, "log_mel_spectrogram", lambda audio, n_mels=80, padding=0, device=None: other(audio, n_mels, padding, device) * 0.9)
+    with backend.gpu_log_mel("cuda:0", enabled=True) as on:
+        assert on is False
+
+
 def test_fused_attention_self_check_catches_a_backend_with_another_scaling(monkeypatch):
     """The once-per-session check of the fused path against the backend's own unfused attention: a backend whose
     attention scales differently from d_head ** -0.25 on q and k must be refused loudly, not aligned on wrong rows."""

@@ -156,7 +156,7 @@ def test_package_surface_like_the_reference():
         wt.no_such_name
 
 
-def test_gpu_log_mel_patch_is_scoped():
+def test_gpu_log_mel_patch_is_scoped(monkeypatch):
     """backend.gpu_log_mel instruments the backend's transcribe module only inside the context (also on errors)."""
     import sys
     import whisper_double
@@ -164,6 +164,9 @@ def test_gpu_log_mel_patch_is_scoped():
     from whisper_timestamped import backend
     mod = sys.modules["whisper.transcribe"]
     original = mod.log_mel_spectrogram
+    with backend.gpu_log_mel("cuda:0", enabled=True) as on:      # no GPU here: the front-end self-check cannot pass,
+        assert on is False and mod.log_mel_spectrogram is original   # so the backend keeps its own log-mel
+    monkeypatch.setattr(backend, "_front_end_matches", lambda *a, **k: True)
     with backend.gpu_log_mel("cuda:0", enabled=False) as on:
         assert on is False and mod.log_mel_spectrogram is original
     with pytest.raises(RuntimeError):

@@ -81,6 +81,35 @@ def should_use_space(language) -> bool:
     return norm_language(language) not in ["zh", "ja", "th", "lo", "my", "yue"]
 
 
+_FRONT_END_OK = {}
+
+
+def _front_end_matches(original, wt_audio, device, n_mels=80):
+    """Once per process and backend function: the HIP front end must reproduce THIS backend's log_mel_spectrogram on a
+    probe signal (2 s of noise + a tone; bar 1e-3, observed 3e-5).  A backend with another window / hop / filterbank
+    than the one wt_logmel_batch restates is detected here instead of silently shifting every log-mel."""
+    key = id(original)
+    if key not in _FRONT_END_OK:
+        import logging
+        import torch
+        try:
+            g = torch.Generator().manual_seed(0)
+            t = torch.arange(32000) / 16000.0
+            probe = (0.05 * torch.randn(32000, generator=g) + 0.1 * torch.sin(2 * 3.141592653589793 * 440.0 * t)).float()
+            want = original(probe, n_mels).float().cpu()
+            got = wt_audio.log_mel_spectrogram(probe, n_mels=n_mels, device=device).float().cpu()
+            ok = want.shape == got.shape and float((want - got).abs().max()) <= 1e-3
+        except Exception as err:  # noqa: BLE001 -- whatever an unknown backend raises
+            ok = False
+            logging.getLogger("whisper_timestamped").warning(f"GPU front end self-check could not run ({err})")
+        if not ok:
+            logging.getLogger("whisper_timestamped").warning(
+                "whisper_timestamped: this backend's log_mel_spectrogram differs from the HIP front end; "
+                "using the backend's own (efficient.GPU_FRONT_END is ignored)")
+        _FRONT_END_OK[key] = ok
+    return _FRONT_END_OK[key]
+
+
 @contextmanager
 def gpu_log_mel(device, enabled=True):
     """While decoding, route openai-whisper's own ``log_mel_spectrogram`` call (whisper/transcribe.py: one call
@@ -94,6 +123,9 @@ def gpu_log_mel(device, enabled=True):
         return
     from . import audio as wt_audio
     original = mod.log_mel_spectrogram
+    if not _front_end_matches(original, wt_audio, device):
+        yield False                      # this backend's front end is not the one wt_logmel_batch restates: keep its own
+        return
 
     def log_mel_on_gpu(audio, n_mels=80, padding=0, device=None):
         if isinstance(audio, str):
