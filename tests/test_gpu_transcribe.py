@@ -137,8 +137,26 @@ def test_capture_ring_rows_match_reference_hook():
     assert torch.equal(gathered[:, 1], ring.buf[:, 2])
 
 
+def test_transcribe_with_the_reference_way_of_computing_logits(monkeypatch):
+    """efficient.REUSE_DECODER_LOGITS = False: the reference's second projection + filter pass per token (the default,
+    "auto", reuses the decoder's rows after verifying the first token of every window: the parametrised cases above)."""
+    from whisper_timestamped import efficient
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", False)
+    for name in ("two_windows_prompted", "decoding_limit", "language_detection", "no_speech_skip"):
+        case = _by_name(name)
+        got = run_case(case, device="cuda:0")
+        dt, dc = compare(got, case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4)
+        assert efficient.LAST_SESSION["windows_verified"] == 0
+        _report(name + "[reference-way logits]", dt, dc)
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", "auto")
+    case = _by_name("three_windows_single_segment_window")
+    run_case(case, device="cuda:0")
+    assert efficient.LAST_SESSION["windows_verified"] == 3 and not efficient.LAST_SESSION["reuse_fell_back"]
+    assert efficient.LAST_SESSION["alignment_launch_sets"] == 3
+
+
 def test_transcribe_reusing_decoder_logits(monkeypatch):
-    """Opt-in: no second projection + filter pass per token (efficient.REUSE_DECODER_LOGITS)."""
+    """No verification pass at all (efficient.REUSE_DECODER_LOGITS = True)."""
     from whisper_timestamped import efficient
     monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", True)
     for name in ("two_windows_prompted", "decoding_limit", "language_detection", "no_trust_whisper_timestamps"):

@@ -116,6 +116,49 @@ def test_reusing_the_decoder_logits_gives_the_same_result(case, monkeypatch):
     compare(got, case["expected"], time_tol=0.0, conf_tol=1e-3 + 1e-9, logprob_tol=1e-5)
 
 
+def test_logits_reuse_verifies_itself_window_by_window(monkeypatch):
+    """efficient.REUSE_DECODER_LOGITS = "auto" (default): every 30 s window's first token is done both ways; with a backend
+    that filters in place the rest of the window reuses the decoder's rows, and one alignment launch set per window."""
+    from whisper_timestamped import efficient
+    cpu_kernel_standin.install(monkeypatch)
+    case = next(c for c in CASES if c["name"] == "three_windows_single_segment_window")
+    got = run_case(copy.deepcopy(case))
+    compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+    assert efficient.LAST_SESSION["reuse_mode"] == "auto" and not efficient.LAST_SESSION["reuse_fell_back"]
+    assert efficient.LAST_SESSION["windows_verified"] == 3 and efficient.LAST_SESSION["alignment_launch_sets"] == 3
+
+
+def test_logits_reuse_falls_back_when_the_backend_filters_a_copy(monkeypatch):
+    """A backend whose sampler filters a COPY of the decoder's logits: the first token's comparison fails, the session
+    goes back to the reference's per-token projection + filters -- and the result is still the reference's."""
+    import whisper_double as W
+    from whisper_timestamped import efficient
+    cpu_kernel_standin.install(monkeypatch)
+    W.install()
+    inner = W.decoding.PyTorchInference.logits
+    monkeypatch.setattr(W.decoding.PyTorchInference, "logits", lambda self, tokens, af: inner(self, tokens, af).clone())
+    for name in ("two_windows_prompted", "decoding_limit"):
+        case = next(c for c in CASES if c["name"] == name)
+        got = run_case(copy.deepcopy(case))
+        compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+        assert efficient.LAST_SESSION["reuse_fell_back"] and efficient.LAST_SESSION["reuse_state"] == "off"
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", True)          # forced reuse on such a backend: refused loudly
+    with pytest.raises(RuntimeError, match="does not filter the decoder's logits in place"):
+        run_case(copy.deepcopy(next(c for c in CASES if c["name"] == "two_windows_prompted")))
+
+
+def test_the_reference_way_of_computing_the_logits(monkeypatch):
+    """efficient.REUSE_DECODER_LOGITS = False: a second projection + filter pass per token, exactly as the reference."""
+    from whisper_timestamped import efficient
+    cpu_kernel_standin.install(monkeypatch)
+    monkeypatch.setattr(efficient, "REUSE_DECODER_LOGITS", False)
+    for name in ("two_windows_prompted", "no_speech_skip", "language_detection", "eot_without_end_timestamp"):
+        case = next(c for c in CASES if c["name"] == name)
+        got = run_case(copy.deepcopy(case))
+        compare(got, case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+        assert efficient.LAST_SESSION["windows_verified"] == 0
+
+
 def test_segment_by_segment_alignment_gives_the_same_result(monkeypatch):
     """efficient.DEFER_ALIGNMENT = False: one synchronous alignment per flushed segment (the reference's shape) instead of
     one launch set per window read a window later -- same output."""

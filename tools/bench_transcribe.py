@@ -5,12 +5,14 @@ Times, for one 30 s clip and a scripted ~110-token transcript on a whisper-base-
   plain      : the backend's own transcribe() (no hooks)
   unfused    : this repository's transcribe() with efficient.FUSED_ATTENTION = False (qk observed inside
                whisper.model.disable_sdpa(), the only way the reference can get it)
-  timestamped: this repository's transcribe() (wt_qk_rows + filtered-logit ring + HIP alignment per segment)
-  reuse      : the same with efficient.REUSE_DECODER_LOGITS (no second projection + filter pass per token)
+  timestamped: this repository's transcribe() with its defaults (wt_qk_rows_batch per token, logits reuse verified on
+               the first token of every window, one alignment launch set per window)
+  reuse      : efficient.REUSE_DECODER_LOGITS = True (no verification pass at all)
+  no_reuse   : efficient.REUSE_DECODER_LOGITS = False (the reference's second projection + filter pass per token)
   per_segment: timestamped with efficient.DEFER_ALIGNMENT = False (one synchronous alignment per flushed segment)
 Prints one JSON line.  The decode loop itself is the backend's Python loop (batch 1), as with the reference.
 
-usage: bench_transcribe.py [base|small|...] [--only plain|timestamped|unfused|reuse|per_segment]
+usage: bench_transcribe.py [base|small|...] [--only plain|timestamped|unfused|reuse|no_reuse|per_segment]
        (--only: that variant alone, for a rocprofv3 --kernel-trace of exactly one data plane)
 """
 import json
@@ -67,7 +69,7 @@ def main():
                 with torch.no_grad():
                     return model.transcribe(audio, language="en", temperature=0.0, fp16=False)
             efficient.FUSED_ATTENTION = only != "unfused"
-            efficient.REUSE_DECODER_LOGITS = only == "reuse"
+            efficient.REUSE_DECODER_LOGITS = True if only == "reuse" else False if only in ("no_reuse", "unfused") else "auto"
             efficient.DEFER_ALIGNMENT = only != "per_segment"
             return wt.transcribe(model, audio, language="en", fp16=False)
         t, _ = timed(variant, reps=4)
@@ -76,22 +78,29 @@ def main():
         return
     with torch.no_grad():
         t_plain, _ = timed(lambda: model.transcribe(audio, language="en", temperature=0.0, fp16=False))
-    efficient.FUSED_ATTENTION = False             # the reference's way: every attention module unfused, qk observed
+    efficient.FUSED_ATTENTION = False             # the reference's way: every attention module unfused, qk observed,
+    efficient.REUSE_DECODER_LOGITS = False        # a second projection + filter pass per token
     t_unfused, res0 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
     efficient.FUSED_ATTENTION = True
+    t_noreuse, res4 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    efficient.REUSE_DECODER_LOGITS = "auto"       # the defaults
     t_ts, res = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
+    stats = dict(efficient.LAST_SESSION)
     efficient.REUSE_DECODER_LOGITS = True
     t_reuse, res2 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
-    efficient.REUSE_DECODER_LOGITS = False
+    efficient.REUSE_DECODER_LOGITS = "auto"
     efficient.DEFER_ALIGNMENT = False
     t_seg, res3 = timed(lambda: wt.transcribe(model, audio, language="en", fp16=False))
     efficient.DEFER_ALIGNMENT = True
     words = sum(len(s.get("words", [])) for s in res["segments"])
     starts = lambda r: [(w["start"], w["end"]) for s in r["segments"] for w in s["words"]]  # noqa: E731
-    same = starts(res) == starts(res2) == starts(res0) == starts(res3)
+    same = starts(res) == starts(res2) == starts(res0) == starts(res3) == starts(res4)
     print(json.dumps(dict(model=f"whisper-{name} shapes (random init)", tokens=n_tokens, segments=len(res["segments"]), words=words,
                           plain_s=round(t_plain, 4), timestamped_unfused_attention_s=round(t_unfused, 4),
                           timestamped_s=round(t_ts, 4), timestamped_reuse_s=round(t_reuse, 4),
+                          timestamped_reference_logits_s=round(t_noreuse, 4),
+                          overhead_reference_logits_pct=round(100 * (t_noreuse / t_plain - 1), 1),
+                          default_session=stats,
                           timestamped_per_segment_sync_s=round(t_seg, 4),
                           overhead_per_segment_sync_pct=round(100 * (t_seg / t_plain - 1), 1),
                           overhead_unfused_attention_pct=round(100 * (t_unfused / t_plain - 1), 1),

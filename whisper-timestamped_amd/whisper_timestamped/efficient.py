@@ -31,17 +31,25 @@ from .words import HOP_LENGTH, N_AUDIO_CTX, SAMPLE_RATE
 
 logger = logging.getLogger("whisper_timestamped")
 
+# what the last EfficientSession did (tests / diagnostics): windows whose first token verified the logits reuse,
+# whether the session fell back to the reference's per-token projection, alignment launch sets
+LAST_SESSION = {}
+
 # storage type of the captured cross-attention rows: float32 = what the reference sees (qk.float());
 # float16 halves the HBM bytes of the cost kernel (build-side option, BASELINE config 5; parity quantified in tests)
 RING_DTYPE = torch.float32
 # compute whisper's whole-file log-mel with the HIP front end instead of torch.stft (backend.gpu_log_mel)
 GPU_FRONT_END = True
-# Opt-in: take the step's filtered logits from the decoder itself instead of re-projecting ln's output and
-# re-applying the logit filters as the reference does (transcribe.py:871-874 duplicates, once per token, a D x V
-# GEMV and the filters whisper's sampler has just applied in place to the tensor the decoder returned).  The row is
-# read one step later, when the sampler is done with it.  Same values up to GEMM-vs-GEMV rounding of the first
-# step of a window; off by default because it relies on the backend filtering IN PLACE.
-REUSE_DECODER_LOGITS = False
+# Take the step's filtered logits from the decoder itself instead of re-projecting ln's output and re-applying the logit
+# filters as the reference does (transcribe.py:871-874 duplicates, once per token, a D x V GEMV and the filters
+# whisper's sampler has just applied IN PLACE to the tensor the decoder returned).  The row is read one step later, when
+# the sampler is done with it.  Same values up to GEMM-vs-GEMV rounding of the first step of a window.
+#   "auto" (default): the first token of every 30 s window is done BOTH ways and the two rows are compared (same -inf
+#       pattern, same values); if they agree the rest of the window reuses the decoder's rows, if they ever do not
+#       (a backend that does not filter in place, other filters ...) the session goes back to the reference's way
+#       for good -- nothing is lost, the verified row of that token is the reference-way one;
+#   True: always reuse (raises if the backend visibly does not filter in place);  False: the reference's way.
+REUSE_DECODER_LOGITS = "auto"
 # Compute the alignment heads' QK rows from cross_attn.query / cross_attn.key outputs (wt_qk_rows) and let the backend
 # keep its fused attention.  The reference reads qk from MultiHeadAttention's second output, which only exists on the
 # unfused path: it runs EVERY attention module of the model (encoder included) unfused, inside
@@ -117,6 +125,10 @@ class EfficientSession:
         self._k = [None] * len(self.hooked_blocks)
         self._v = [None] * len(self.hooked_blocks)     # only until the fused path has been checked once
         self._fused_checked = False
+        self.reuse = REUSE_DECODER_LOGITS
+        self.reuse_state = "verify"          # "auto": verify (first token of a window) -> trusted | off (for good)
+        self._verify_row = None
+        self.stats = dict(reuse_mode=self.reuse, windows_verified=0, reuse_fell_back=False, alignment_launch_sets=0)
         # deferred alignment: units queued during the window, launched when it closes, collected one window later
         self.defer = DEFER_ALIGNMENT and not detect_disfluencies
         self.workspace = default_workspace(dev)    # pinned staging + result buffers survive from call to call
@@ -235,6 +247,8 @@ class EfficientSession:
 
     def hook_decoder_logits(self, layer, ins, outs):
         """REUSE_DECODER_LOGITS: forward hook on model.decoder; outs = (1, n_q, V) fp32 logits, not yet filtered."""
+        if self.reuse == "auto" and self.reuse_state == "off":
+            return                                    # the reference's way took over (hook_decoder_output)
         tk = self.tokenizer
         if self.sot_index is not None and self.no_speech_prob is None:
             self.no_speech_prob = outs[0, self.sot_index].float().softmax(dim=-1)[tk.no_speech].item()
@@ -251,15 +265,53 @@ class EfficientSession:
             return
         outs, at_limit = self.pending_logits
         self.pending_logits = None
-        self.logits.append(outs[0, -1])
-        if len(self.logits) == 1 and self.tokenizer.no_timestamps is not None:
+        row = outs[0, -1]
+        if self.reuse == "auto" and self.reuse_state == "verify":
+            row = self._verified(row)
+        self.logits.append(row)
+        if self.reuse is True and len(self.logits) == 1 and self.tokenizer.no_timestamps is not None:
             # once per window: the row must carry the sampler's in-place filtering (<|notimestamps|> is always -inf)
             if not bool(torch.isinf(self.logits.buf[0, self.tokenizer.no_timestamps])):
                 raise RuntimeError("REUSE_DECODER_LOGITS: this backend does not filter the decoder's logits in place; "
                                    "set whisper_timestamped.efficient.REUSE_DECODER_LOGITS = False")
         self.last_chunk_token = self.logits.argmax(-1) if at_limit else None
 
+    def _verified(self, row):
+        """First token of a window, "auto": the decoder's row as the sampler left it against the reference-way row of
+        the same step (self._verify_row).  -> the row to keep."""
+        want = self._verify_row
+        self._verify_row = None
+        if want is None:
+            self.reuse_state = "off"
+            return row
+        want = want.reshape(-1)
+        fin = torch.isfinite(want)
+        tol = 1e-3 if self.embedding_t.dtype == torch.float32 else 5e-2
+        same = bool(torch.equal(fin, torch.isfinite(row))) and bool(((row[fin] - want[fin]).abs() <= tol).all())
+        if same:
+            self.reuse_state = "trusted"
+            self.stats["windows_verified"] += 1
+            return row
+        self.reuse_state = "off"
+        self.stats["reuse_fell_back"] = True
+        logger.warning("whisper_timestamped: the decoder's logits do not carry the sampler's filtering (or differ from the "
+                       "re-projected ones): falling back to the reference's per-token projection + filter pass")
+        return want
+
     def hook_decoder_output(self, layer, ins, outs):
+        if self.reuse == "auto":
+            if self.reuse_state == "trusted":
+                return                               # the decoder's own rows are being reused
+            if self.reuse_state == "verify":
+                if self.has_started:                  # the reference-way row of this step, kept aside for _verified()
+                    if self.embedding_t is None:
+                        self.embedding_t = torch.transpose(self.model.decoder.token_embedding.weight, 0, 1).to(outs[0].dtype)
+                    row = (outs[0][-1:, :] @ self.embedding_t).float()
+                    context = self.ctx_buf[:, :self.ctx_len]
+                    for f in self.logit_filters:
+                        f.apply(row, context)
+                    self._verify_row = row
+                return
         tk = self.tokenizer
         if self.embedding_t is None:
             self.embedding_t = torch.transpose(self.model.decoder.token_embedding.weight, 0, 1).to(outs[0].dtype)
@@ -423,6 +475,7 @@ class EfficientSession:
                     set_padding(unit, None if sp < 0 else sp)
                 batch.add(unit)
             batch.launch().fetch()
+            self.stats["alignment_launch_sets"] += 1
             self.in_flight.append((batch, [ws for _, ws, _ in self.queued]))
             self.queued = []
         self._collect(previous)
@@ -611,6 +664,8 @@ class EfficientSession:
         self.window_tokens_nosot = []
         self.logits.reset()
         self.no_speech_prob = None
+        if self.reuse_state == "trusted":
+            self.reuse_state = "verify"          # every window proves itself on its first token
 
     # ------------------------------------------------------------------ driver
     def run(self, audio):
@@ -631,9 +686,9 @@ class EfficientSession:
                     hooks.append(ca.register_forward_hook(
                         lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
             if self.compute_word_confidence or self.no_speech_threshold is not None:
-                if REUSE_DECODER_LOGITS:
+                if self.reuse in (True, "auto"):
                     hooks.append(model.decoder.register_forward_hook(self.hook_decoder_logits))
-                else:
+                if self.reuse in (False, "auto"):
                     hooks.append(model.decoder.ln.register_forward_hook(self.hook_decoder_output))
             with torch.no_grad(), backend.attention_weights_exposed(not FUSED_ATTENTION), \
                     backend.gpu_log_mel(model.device, GPU_FRONT_END):
@@ -646,6 +701,8 @@ class EfficientSession:
         if self.defer:
             self._resolve_all()                   # the last window's record
         self.segment_tokens.pop(-1)
+        LAST_SESSION.clear()
+        LAST_SESSION.update(self.stats, reuse_state=self.reuse_state)
         return self._compile(transcription)
 
     def _compile(self, transcription):
