@@ -125,6 +125,7 @@ class EfficientSession:
         self._k = [None] * len(self.hooked_blocks)
         self._v = [None] * len(self.hooked_blocks)     # only until the fused path has been checked once
         self._fused_checked = False
+        self._value_hooks = []
         self.reuse = REUSE_DECODER_LOGITS
         self.reuse_state = "verify"          # "auto": verify (first token of a window) -> trusted | off (for good)
         self._verify_row = None
@@ -211,11 +212,14 @@ class EfficientSession:
         self.ring.write(index, qk, self.open_rows[-1])
 
     def hook_cross_attention_fused(self, index, layer, ins, outs):
-        # the last hooked layer has run: q / K of every hooked layer are known -> ONE launch for all of them
-        if self.has_started and index == len(self.hooked_blocks) - 1:
+        # the last layer that owns a selected head has run: q / K of all of them are known -> ONE launch for all
+        if self.has_started:
             self.ring.write_all_layers(self._q, self._k, self.open_rows[-1])
             if not self._fused_checked:
                 self._check_fused_rows(self.open_rows[-1])
+                for h in self._value_hooks:           # only needed for that one comparison
+                    h.remove()
+                self._value_hooks = []
 
     def _check_fused_rows(self, row):
         """Once per session: the rows wt_qk_rows computes from cross_attn.query / cross_attn.key must be the qk the
@@ -239,7 +243,8 @@ class EfficientSession:
                 worst = max(worst, float((got - want).abs().max()))
         self._v = [None] * len(self.hooked_blocks)
         # (a half-precision model or a half-precision ring rounds the rows themselves: 2^-11 of |qk| ~ 10)
-        tol = 2e-3 if (self._q[0].dtype == torch.float32 and self.ring.buf.dtype == torch.float32) else 0.1
+        q_any = next(q for q in self._q if q is not None)
+        tol = 2e-3 if (q_any.dtype == torch.float32 and self.ring.buf.dtype == torch.float32) else 0.1
         if not worst <= tol:
             raise RuntimeError(f"FUSED_ATTENTION self-check failed: the QK rows computed from cross_attn.query/key differ "
                                f"from the backend's own unfused attention by {worst:.3g} (> {tol}); set "
@@ -673,15 +678,19 @@ class EfficientSession:
         hooks = [model.encoder.conv1.register_forward_hook(self.hook_mel),
                  model.decoder.token_embedding.register_forward_hook(self.hook_tokens)]
         try:
+            used = self.ring.used_layers()               # layers that own a selected head: the only ones observed
             for j, b in enumerate(self.hooked_blocks):
                 ca = model.decoder.blocks[b].cross_attn
                 if FUSED_ATTENTION:
+                    if j not in used:
+                        continue
                     hooks.append(ca.query.register_forward_hook(lambda m, i, o, index=j: self._q.__setitem__(index, o)))
                     hooks.append(ca.key.register_forward_hook(lambda m, i, o, index=j: self._k.__setitem__(index, o)))
-                    hooks.append(ca.value.register_forward_hook(
-                        lambda m, i, o, index=j: None if self._fused_checked else self._v.__setitem__(index, o)))
-                    hooks.append(ca.register_forward_hook(
-                        lambda layer, ins, outs, index=j: self.hook_cross_attention_fused(index, layer, ins, outs)))
+                    self._value_hooks.append(ca.value.register_forward_hook(
+                        lambda m, i, o, index=j: self._v.__setitem__(index, o)))
+                    if j == used[-1]:
+                        hooks.append(ca.register_forward_hook(
+                            lambda layer, ins, outs, index=j: self.hook_cross_attention_fused(index, layer, ins, outs)))
                 else:
                     hooks.append(ca.register_forward_hook(
                         lambda layer, ins, outs, index=j: self.hook_cross_attention(index, layer, ins, outs)))
@@ -694,8 +703,9 @@ class EfficientSession:
                     backend.gpu_log_mel(model.device, GPU_FRONT_END):
                 transcription = model.transcribe(audio, **self.opts)
         finally:
-            for h in hooks:
+            for h in hooks + self._value_hooks:
                 h.remove()
+            self._value_hooks = []
         self._commit_pending_logits()
         self._may_flush()
         if self.defer:
