@@ -499,19 +499,24 @@ def run_e2e(dev, args, rank, world, dist):
     out.update(fp32)
     out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
     # the reference's GPU default is fp16=True (transcribe.py:240-241): the same pipeline with half-precision
-    # activations -- whisper keeps LayerNorm in fp32 and casts the other weights per call; here they are cast once
-    for m in model.modules():
-        if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
-            m.half()
-    res16, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
-    out["fp16_model"] = fp16
-    # ... and with the forward pass replayed as ONE captured HIP graph (the eager half-precision pass is bound by the
-    # Python dispatch of ~300 small launches, not by the GPU)
-    res_g, fp16g = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, forward_graph=True, **opts), "fp16 graph")
-    fp16g["words_equal_the_eager_pass"] = all([w["text"] for w in a.words] == [w["text"] for w in b.words] and
-                                              all(abs(x["start"] - y["start"]) <= 0.02 and abs(x["end"] - y["end"]) <= 0.02
-                                                  for x, y in zip(a.words, b.words)) for a, b in zip(res_g, res16))
-    out["fp16_model_forward_as_hip_graph"] = fp16g
+    # activations -- whisper keeps LayerNorm in fp32 and casts the other weights per call; here they are cast once.
+    # These two legs are extras: a failure in them is reported in the line instead of costing the line.
+    try:
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
+                m.half()
+        res16, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
+        out["fp16_model"] = fp16
+        # ... and with the forward pass replayed as ONE captured HIP graph (the eager half-precision pass is bound by
+        # the Python dispatch of ~300 small launches, not by the GPU)
+        res_g, fp16g = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, forward_graph=True, **opts), "fp16 graph")
+        fp16g["words_equal_the_eager_pass"] = all(
+            [w["text"] for w in a.words] == [w["text"] for w in b.words] and
+            all(abs(x["start"] - y["start"]) <= 0.02 and abs(x["end"] - y["end"]) <= 0.02 for x, y in zip(a.words, b.words))
+            for a, b in zip(res_g, res16))
+        out["fp16_model_forward_as_hip_graph"] = fp16g
+    except Exception as err:  # noqa: BLE001
+        out["fp16_legs_error"] = f"{type(err).__name__}: {err}"[:300]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same chunks through the reference-shaped CPU path, bounded sample
