@@ -108,6 +108,49 @@ def _one_rank_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
+def _islands_two_ranks_gloo_worker(rank, world, port, out_path):
+    """Two processes on the ONE GPU of the box, real kernels, collectives over gloo (RCCL refuses two ranks on one
+    device): the island job's weight / audio broadcasts carry GPU tensors, the result gather is the object gather."""
+    for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        job = _islands_job()
+        t0 = time.perf_counter()
+        result, seen = _run_islands_job(dist, job, None, device="cuda:0")
+        wall = time.perf_counter() - t0
+        owned = [None] * world
+        dist.all_gather_object(owned, seen)
+        assert sorted(i for part in owned for i in part) == [0, 1, 2, 3] and all(len(part) > 0 for part in owned)
+        if rank == 0:
+            dt, dc = _check_islands_result(result, job, time_tol=0.02, conf_tol=1e-3 + 1e-4)
+            with open(out_path, "w") as f:
+                json.dump({"backend": "gloo (collectives) + MI355X kernels", "world": world, "islands_per_rank": owned,
+                           "islands_max_abs_dt_s": round(dt, 4), "islands_max_abs_dconfidence": round(dc, 5),
+                           "islands_job_s": round(wall, 3)}, f)
+        else:
+            assert result is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_islands_job_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
+    """The sharded long-form job with TWO ranks and the real kernels (both processes on cuda:0; gloo carries the
+    collectives because RCCL does not accept two ranks on one device): islands dealt to both ranks, rank 1 starts from
+    garbage weights and no audio, the merged result equals the reference's per-island output."""
+    out = tmp_path / "gloo2.json"
+    mp.spawn(_islands_two_ranks_gloo_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    report = json.loads(out.read_text())
+    assert report["islands_max_abs_dt_s"] <= 0.02 and all(len(p) > 0 for p in report["islands_per_rank"])
+    _keep(report, "islands_two_ranks_one_gpu_gloo.json")
+
+
 def _keep(report, name):
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
