@@ -488,6 +488,7 @@ def run_e2e(dev, args, rank, world, dist):
         return res, {"audio_s_per_s": round(world * 30.0 * len(jobs) / el, 1), "ms_per_launch_set": round(el / steps * 1e3, 3),
                      "gpu_kernel_ms_per_launch_set": round(gpu_ms, 3),
                      "gpu_stage_ms": {k: round(v, 3) for k, v in stage.items()},
+                     "alignment_share": round(align_ms / gpu_ms, 4) if gpu_ms else None,      # of the GPU kernel time
                      "alignment_share_of_gpu_time": round(align_ms / gpu_ms, 4) if gpu_ms else None,
                      "gpu_span_ms_per_launch_set": round(span_ms, 3),
                      "gpu_busy_fraction_of_wall": round(min(1.0, gpu_ms * steps / (el * 1e3)), 4),
@@ -551,7 +552,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="kfull", choices=sorted(WORKLOADS) + ["e2e_base32"],
+                    help="kfull (default; its line also carries the transcribe()-level leg), the secondary kernel-level workloads, "
+                         "or e2e_base32 = kfull with the e2e leg forced on")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="the --steps region is repeated until this much time has been measured (>= 5 regions)")
     ap.add_argument("--repeats", type=int, default=0, help="fixed number of timed regions (0 = from --min-seconds)")
@@ -595,6 +598,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "e2e_base32":
+        args.workload, args.e2e = "kfull", "on"
     cfg = WORKLOADS[args.workload]
     w = make_workload(dev, cfg, seed=1234 + rank)
     n = cfg["n_chunks"]
