@@ -605,7 +605,7 @@ def main():
     n = cfg["n_chunks"]
     cfg = w["cfg"]
 
-    if args.graph or args.overlap != "none":
+    if args.overlap != "none":
         args.pipeline = 1
     gatherers = None
     if world > 1 or force_dist:
@@ -661,15 +661,27 @@ def main():
 
     graph = None
     if args.graph:
-        assert args.overlap == "none" and gather_buf is None, "--graph: single stream, single rank"
+        # ONE captured HIP graph holding `pipeline` steps: batch 0 on the capture stream, every other batch on a branch
+        # forked at the head of the graph and joined at its end (independent branches: the runtime may run them side by
+        # side, as the eager two-stream pipeline does, without the per-launch host cost)
+        assert args.overlap == "none" and gather_buf is None, "--graph: single rank"
         cap = torch.cuda.Stream(device=dev)
+        sides = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline - 1)]
         cap.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cap):                 # the library's scratch arenas are per stream: create them
-            run_step(w, None, None)                  # (hipMalloc) before the capture, not inside it
-        cap.synchronize()
+        for j, s_ in enumerate([cap] + sides):       # the library's scratch arenas are per stream: create them
+            with torch.cuda.stream(s_):              # (hipMalloc) before the capture, not inside it
+                run_step(pipe[j], None, None)
+        torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=cap):
-            run_step(w, None, None)
+            for s_ in sides:
+                s_.wait_stream(cap)                  # fork
+            run_step(pipe[0], None, None)
+            for j, s_ in enumerate(sides, 1):
+                with torch.cuda.stream(s_):
+                    run_step(pipe[j], None, None)
+            for s_ in sides:
+                cap.wait_stream(s_)                  # join
         graph.replay()
         torch.cuda.synchronize()
 
@@ -689,9 +701,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if graph is not None:
-            for k in range(args.steps):
+        if graph is not None and (pipelined or args.pipeline == 1):
+            reps, rem = divmod(args.steps, args.pipeline)     # one replay = `pipeline` steps
+            for k in range(reps):
                 graph.replay()
+            for k in range(rem):
+                full_step(None, k, args.pipeline > 1)
         else:
             for k in range(args.steps):
                 full_step(None if pipelined else evs[k], k, pipelined)
@@ -706,12 +721,12 @@ def main():
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        if graph is None and not pipelined:
+        if not pipelined and (graph is None or args.pipeline > 1):
             for s in STAGES:
                 stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
         return el
 
-    if graph is not None:                            # eager pass for the per-stage breakdown (NOT part of the timing)
+    if graph is not None and args.pipeline == 1:     # eager pass for the per-stage breakdown (NOT part of the timing)
         for k in range(args.steps):
             full_step(evs[k])
         torch.cuda.synchronize()
