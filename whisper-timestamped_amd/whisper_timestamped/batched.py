@@ -96,7 +96,10 @@ class BatchedAligner:
         self.n_ctx = model.dims.n_audio_ctx
         self.pairs = head_pairs(alignment_heads)
         per_layer, self.n_slots = layer_head_slots(self.pairs, len(self.hooked), self.n_heads)
-        sel = [(l, h, s) for l, (hs, ss) in enumerate(per_layer) for h, s in zip(hs, ss)]
+        # only the layers that own a selected head are observed (whisper-small: 4 of 12, large-v3: 10 of 32 -- every
+        # observed layer keeps its (B, 1500, D) key projection alive until the rows are computed)
+        self.used = [l for l, (hs, _) in enumerate(per_layer) if hs]
+        sel = [(i, h, s) for i, l in enumerate(self.used) for h, s in zip(*per_layer[l])]
         self.sel_layer, self.sel_head, self.sel_slot = (
             torch.tensor([x[i] for x in sel], dtype=torch.int32, device=self.dev) for i in range(3))
         self.refine, self.remove_punct = refine_whisper_precision_nframes, remove_punctuation_from_words
@@ -148,11 +151,12 @@ class BatchedAligner:
     # ------------------------------------------------------------------ the model's forward pass
     def _forward(self, x, tok_dev):
         """-> (logits (B, T, V), q_out, k_out, captured): eager, with the capture hooks installed for the call."""
-        q_out, k_out, captured = [None] * len(self.hooked), [None] * len(self.hooked), [None] * len(self.hooked)
+        n = len(self.used)
+        q_out, k_out, captured = [None] * n, [None] * n, [None] * n
         hooks = []
         try:
-            for j, blk in enumerate(self.hooked):
-                ca = self.model.decoder.blocks[blk].cross_attn
+            for j, l in enumerate(self.used):
+                ca = self.model.decoder.blocks[self.hooked[l]].cross_attn
                 if self.fused:
                     hooks.append(ca.query.register_forward_hook(lambda m, i, o, j=j: q_out.__setitem__(j, o)))
                     hooks.append(ca.key.register_forward_hook(lambda m, i, o, j=j: k_out.__setitem__(j, o)))
