@@ -41,20 +41,32 @@ __device__ __forceinline__ float med3f(float a, float b, float c) { return __bui
 // Asynchronous copy of one head's row (F logits) into dst[4 .. 4+F): fp32 goes
 // HBM -> LDS directly (global_load_lds, no VGPR round trip, completion tracked by
 // vmcnt); fp16 (a build-side storage option) is converted through registers.
+// 16 bytes per lane and instruction (global_load_lds_dwordx4: lane l of a load lands at base + 16*l): a 1500-frame row
+// is 6 instructions instead of 24.  Groups of four floats that do not lie fully inside the row re-read the last full
+// group (their LDS slots are never used) -- except that the straddling group's slots hold the row's last F % 4
+// elements: those come through a register (`tail`, lanes 0..2) and are written by the caller once the row has landed.
+// Rows shorter than 4 frames take the dword form.  Returns this lane's tail element (meaningful for lane < F % 4).
 template <int C>
-__device__ __forceinline__ void stage_row(const float *__restrict__ src, float *dst, int F, int nch, int lane) {
+__device__ __forceinline__ float stage_row(const float *__restrict__ src, float *dst, int F, int nch, int lane) {
+    if (F < 4) {   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(lane, F - 1)),
+                                         (__attribute__((address_space(3))) void *)(dst + 4), 4, 0, 2);
+        return 0.f;
+    }
+    const int nvec = F >> 2;
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-        if (k < nch) {  // wave-uniform
-            const int f = min(k * 64 + lane, F - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + f),
-                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 64), 4, 0,
+    for (int k = 0; k < C / 4; ++k) {
+        if (k * 256 < F) {  // wave-uniform
+            const int g = min(k * 64 + lane, nvec - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * g),
+                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 256), 16, 0,
                                              2 /* cpol nt: every logit is read exactly once */);
         }
     }
+    return src[min(4 * nvec + lane, F - 1)];
 }
 template <int C>
-__device__ __forceinline__ void stage_row(const __half *__restrict__ src, float *dst, int F, int nch, int lane) {
+__device__ __forceinline__ float stage_row(const __half *__restrict__ src, float *dst, int F, int nch, int lane) {
     // fp16 storage (build-side option): two halves per lane and load when the row starts on a 4-byte boundary
     // (half the load instructions, full 4-byte lanes), element-wise otherwise; converted through registers.
     if ((reinterpret_cast<uintptr_t>(src) & 3) == 0 && F >= 2) {  // wave-uniform
@@ -70,7 +82,7 @@ __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float 
             if (k * 64 < npair)                          // (clamped lanes write duplicates beyond the pairs: fixed below)
                 *reinterpret_cast<float2 *>(dst + 4 + 2 * (k * 64 + lane)) = __half22float2(v[k]);
         if (lane == 0) dst[4 + F - 1] = last;            // odd F: the unpaired last element (same-wave LDS order)
-        return;
+        return last;
     }
     float v[C];
 #pragma unroll
@@ -78,6 +90,7 @@ __device__ __forceinline__ void stage_row(const __half *__restrict__ src, float 
 #pragma unroll
     for (int k = 0; k < C; ++k)
         if (k < nch) dst[4 + k * 64 + lane] = v[k];
+    return v[0];
 }
 
 // C = elements per lane; an instantiation can serve any F <= C*64 (the launch passes the F range it is used for).
@@ -119,10 +132,14 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     // product this kernel used before: same worst error against the oracle, 2.9e-7 of the matrix maximum; -7 % time)
     const f2 cexp = (f2){qk_scale * 1.44269502162933349609375f, qk_scale * 1.44269502162933349609375f};
 
-    stage_row<C>(row0 + (int64_t)head_idx[0] * d.head_stride, lds[wave][0], F, nch, lane);
+    constexpr bool DMA16 = sizeof(QT) == 4;   // fp32 rows: 16-byte LDS-DMA + a register for the last F % 4 elements
+    const int tail0 = F & ~3, ntail = (DMA16 && F >= 4) ? (F & 3) : 0;
+    float tail = stage_row<C>(row0 + (int64_t)head_idx[0] * d.head_stride, lds[wave][0], F, nch, lane);
     for (int a = 0; a < n_heads; ++a) {
         float *xs = lds[wave][a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
         wait_vmcnt0();                 // head a's row has landed in LDS
+        wave_lds_fence();
+        if (lane < ntail) xs[4 + tail0 + lane] = tail;   // (the group that straddles the end of the row)
         wave_lds_fence();
         if (lane < 8) {
             const float hv = xs[4 + hsrc];
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
         // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
         // that follows an LDS-DMA, which would serialise the copy with the reads.)
         if (a + 1 < n_heads)
-            stage_row<C>(row0 + (int64_t)head_idx[a + 1] * d.head_stride, lds[wave][(a + 1) & 1], F, nch, lane);
+            tail = stage_row<C>(row0 + (int64_t)head_idx[a + 1] * d.head_stride, lds[wave][(a + 1) & 1], F, nch, lane);
         // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
         float lo[C + 6], mi[C + 6], hi[C + 6];
 #pragma unroll
