@@ -55,7 +55,7 @@ __host__ __device__ constexpr float s20(int m) { return c20(m - 5); }  // sin(x)
     } while (0)
 __constant__ float2 k_w400[400];  // [n2][k1] = (cos, sin)(2*pi*n2*k1/400): the twiddle of stage-2 input n2 for output row k1
 
-constexpr int FPB = 12;             // frames per workgroup
+constexpr int FPB = 12;             // frames per workgroup (a multiple of 4: the mel projection reads four frames per tap)
 constexpr int SPAN = 160 * (FPB - 1) + 400;
 constexpr int YP = 21;              // padded row of the stage-1 -> stage-2 exchange
 
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        float *__restrict__ mel_out) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
-    static_assert(FPB * 204 >= SPAN, "the span must fit in the pw buffer");
-    __shared__ float span[FPB * 204];
+    static_assert(FPB * 204 >= SPAN && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
+    __shared__ __attribute__((aligned(16))) float span[FPB * 204];
     __shared__ float2 w400[400];
     __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
     __shared__ float fbw[NNZ_CAP];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     __shared__ unsigned short fb_off[MAX_MELS];
     __shared__ float hann[400];          // window taps: read below with immediate offsets (no per-lane address arithmetic)
     __shared__ float smax[4];
-    float (*pw)[204] = reinterpret_cast<float (*)[204]>(span);
+    float *pw = span;                    // power spectrum, [bin][frame of the tile]: four frames of a bin = one 16-byte read
 
     const int chunk = blockIdx.y;
     const int f0 = blockIdx.x * FPB;
@@ -198,54 +198,90 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
 
     if (act) {
         // ---- stage 1: radix-20 over n1 for this lane's n2 = u (real input, k1 = 0..10) ----
-        // Pair n1 with 20-n1 (cos even, sin odd) and k1 with 10-k1 ((-1)^n1 symmetry): 108 MACs instead of 440.
-        float a[20];
-        const float *fr = span + slot * 160;
+        // Pair n1 with 20-n1 (cos even, sin odd) and k1 with 10-k1 ((-1)^n1 symmetry): 108 MACs instead of 440 -- and
+        // carry them two per instruction (v_pk_*_f32): with e+[n] = a[n] + a[20-n], e-[n] = a[n] - a[20-n],
+        //   Q_k = (Ao, -Be) = sum_j (e+[2j-1], e-[2j]) * ( cos((2j-1)k), -sin(2jk)) + (e+[9] cos(9k), 0)
+        //   R_k = (-Bo, Ae) = sum_j (e-[2j-1], e+[2j]) * (-sin((2j-1)k),  cos(2jk)) + (-e-[9] sin(9k), 0)
+        // and the outputs (re, -im) of rows k and 10-k are swap(R_k + (0, a0 +- a10)) +- Q_k.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        // The twenty samples and window taps are read as the PAIRS the packed arithmetic wants -- (a[2j-1], a[2j]),
+        // (a[21-2j], a[20-2j]), (a0, a9), (a10, a11) -- by ds_read2_b32 with explicit offsets (left to itself hipcc pairs
+        // neighbours (a[2m], a[2m+1]) and spends ~50 v_mov on re-pairing).  Offsets are in dwords (<= 255): second
+        // base at +200 dwords for n1 >= 12.  The compiler does not count these reads: one explicit wait below, tied to
+        // the destination registers so that nothing that uses them is scheduled above it.
+        typedef __attribute__((address_space(3))) const float lds_cf;
+        const unsigned fr0 = (unsigned)(uintptr_t)(lds_cf *)(span + slot * 160 + u), fr1 = fr0 + 800;
+        const unsigned hw0 = (unsigned)(uintptr_t)(lds_cf *)(hann + u), hw1 = hw0 + 800;
+        f2 xa[10], xh[10];
+#define WT_RD2(dst, base, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(base) : "memory")
+        WT_RD2(xa[0], fr0, 20, 40);   WT_RD2(xh[0], hw0, 20, 40);     // U1 = (a1, a2)
+        WT_RD2(xa[1], fr1, 180, 160); WT_RD2(xh[1], hw1, 180, 160);   // V1 = (a19, a18)
+        WT_RD2(xa[2], fr0, 60, 80);   WT_RD2(xh[2], hw0, 60, 80);     // U2 = (a3, a4)
+        WT_RD2(xa[3], fr1, 140, 120); WT_RD2(xh[3], hw1, 140, 120);   // V2 = (a17, a16)
+        WT_RD2(xa[4], fr0, 100, 120); WT_RD2(xh[4], hw0, 100, 120);   // U3 = (a5, a6)
+        WT_RD2(xa[5], fr1, 100, 80);  WT_RD2(xh[5], hw1, 100, 80);    // V3 = (a15, a14)
+        WT_RD2(xa[6], fr0, 140, 160); WT_RD2(xh[6], hw0, 140, 160);   // U4 = (a7, a8)
+        WT_RD2(xa[7], fr1, 60, 40);   WT_RD2(xh[7], hw1, 60, 40);     // V4 = (a13, a12)
+        WT_RD2(xa[8], fr0, 0, 180);   WT_RD2(xh[8], hw0, 0, 180);     // (a0, a9)
+        WT_RD2(xa[9], fr0, 200, 220); WT_RD2(xh[9], hw0, 200, 220);   // (a10, a11)
+#undef WT_RD2
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]),
+                       "+v"(xa[8]), "+v"(xa[9]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xh[4]), "+v"(xh[5]),
+                       "+v"(xh[6]), "+v"(xh[7]), "+v"(xh[8]), "+v"(xh[9]));
+        f2 G[5], H[5];                          // G[j] = (e+[2j-1], e-[2j]),  H[j] = (e-[2j-1], e+[2j]),  j = 1..4
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) a[n1] = fr[20 * n1 + u] * hann[20 * n1 + u];
-        float ep[10], em[10];
-#pragma unroll
-        for (int n = 1; n < 10; ++n) {
-            ep[n] = a[n] + a[20 - n];
-            em[n] = a[n] - a[20 - n];
+        for (int j = 1; j <= 4; ++j) {
+            const f2 U = xa[2 * j - 2] * xh[2 * j - 2], V = xa[2 * j - 1] * xh[2 * j - 1];
+            asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(G[j]) : "v"(U), "v"(V));   // (U.x + V.x, U.y - V.y)
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(H[j]) : "v"(U), "v"(V));   // (U.x - V.x, U.y + V.y)
         }
-        const float base_e = a[0] + a[10], base_o = a[0] - a[10];   // a0 + (-1)^k1 a10
-        float sr[11], si[11];
-#define WT_S1(K)                                                                                          \
-        {                                                                                                 \
-            float Ae = 0.f, Ao = 0.f, Be = 0.f, Bo = 0.f;                                                 \
-            WT_MAC(Ae, ep[2], c20(2 * K)); WT_MAC(Ae, ep[4], c20(4 * K)); WT_MAC(Ae, ep[6], c20(6 * K));  \
-            WT_MAC(Ae, ep[8], c20(8 * K));                                                                \
-            WT_MAC(Ao, ep[1], c20(1 * K)); WT_MAC(Ao, ep[3], c20(3 * K)); WT_MAC(Ao, ep[5], c20(5 * K));  \
-            WT_MAC(Ao, ep[7], c20(7 * K)); WT_MAC(Ao, ep[9], c20(9 * K));                                 \
-            WT_MAC(Be, em[2], s20(2 * K)); WT_MAC(Be, em[4], s20(4 * K)); WT_MAC(Be, em[6], s20(6 * K));  \
-            WT_MAC(Be, em[8], s20(8 * K));                                                                \
-            WT_MAC(Bo, em[1], s20(1 * K)); WT_MAC(Bo, em[3], s20(3 * K)); WT_MAC(Bo, em[5], s20(5 * K));  \
-            WT_MAC(Bo, em[7], s20(7 * K)); WT_MAC(Bo, em[9], s20(9 * K));                                 \
-            const float base = (K & 1) ? base_o : base_e;                                                 \
-            sr[K] = base + Ae + Ao; sr[10 - K] = base + Ae - Ao;                                          \
-            si[K] = Be + Bo;        si[10 - K] = Bo - Be;                                                 \
+        const f2 X09 = xa[8] * xh[8], Y09 = xa[9] * xh[9];
+        const f2 Se = X09 + Y09, So = X09 - Y09;   // (a0 + a10, e+[9]),  (a0 - a10, e-[9])
+        const float ep9 = Se.y, em9 = So.y;
+#define WT_FMA2(acc, x, wx, wy)                                                        \
+    do {                                                                               \
+        constexpr float _wx = (wx), _wy = (wy);                                        \
+        if (_wx != 0.0f || _wy != 0.0f) acc = __builtin_elementwise_fma((x), (f2){_wx, _wy}, acc); \
+    } while (0)
+#define WT_S1(K)                                                                                                  \
+        {                                                                                                         \
+            f2 Q = {0.f, 0.f}, R = {0.f, 0.f};                                                                    \
+            WT_FMA2(Q, G[1], c20(1 * K), -s20(2 * K)); WT_FMA2(Q, G[2], c20(3 * K), -s20(4 * K));                 \
+            WT_FMA2(Q, G[3], c20(5 * K), -s20(6 * K)); WT_FMA2(Q, G[4], c20(7 * K), -s20(8 * K));                 \
+            WT_MAC(Q.x, ep9, c20(9 * K));                                                                         \
+            WT_FMA2(R, H[1], -s20(1 * K), c20(2 * K)); WT_FMA2(R, H[2], -s20(3 * K), c20(4 * K));                 \
+            WT_FMA2(R, H[3], -s20(5 * K), c20(6 * K)); WT_FMA2(R, H[4], -s20(7 * K), c20(8 * K));                 \
+            WT_MAC(R.x, em9, -s20(9 * K));                                                                        \
+            R.y = ((K & 1) ? So.x : Se.x) + R.y;                                                                  \
+            const f2 Rs = {R.y, R.x};                                                                             \
+            const f2 lo = Rs + Q, hi = Rs - Q;                                                                    \
+            yp[slot][K][u] = make_float2(lo.x, lo.y);                                                             \
+            yp[slot][10 - K][u] = make_float2(hi.x, hi.y);                                                        \
         }
         WT_S1(0) WT_S1(1) WT_S1(2) WT_S1(3) WT_S1(4) WT_S1(5)
 #undef WT_S1
-#pragma unroll
-        for (int k1 = 0; k1 <= 10; ++k1) yp[slot][k1][u] = make_float2(sr[k1], -si[k1]);
+#undef WT_FMA2
     }
     __syncthreads();
     if (act) {
         // ---- stage 2: twiddle by W400^(n2*k1), radix-20 over n2 for this lane's k1 = u ----
+        // Rows k1 > 10 are the conjugates of rows 20 - k1 (real input).  Instead of conjugating twenty inputs, such a
+        // lane multiplies by the CONJUGATE twiddle (the table holds it: upload_tables) -- that yields conj(b[n2]) --
+        // and evaluates the radix-20 sums with conjugate roots (the sine terms change sign: `sg` below): the result is
+        // conj(X[k]), whose power is the same.
         const int ks = u <= 10 ? u : 20 - u;
         typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2 cjv = u <= 10 ? (f2){1.f, 1.f} : (f2){1.f, -1.f};   // k1 > 10: the conjugate of row 20 - k1
+        const f2 sg = u <= 10 ? (f2){1.f, -1.f} : (f2){-1.f, 1.f};
         f2 B[20];
         const float2 *wrow = w400 + u;
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) {
             const float2 vv = yp[slot][ks][n2];
-            const float2 ww = wrow[20 * n2];  // (cos, sin) of W400^(n2*u)
+            const float2 ww = wrow[20 * n2];  // (cos, +-sin) of W400^(n2*u)
             // (re + i im)(cos - i sin) = cos*(re, im) + sin*(im, -re): one packed multiply + one packed fma whose
             // operand modifiers do the swap and the sign (hipcc spends a v_xor and a v_mov on them)
-            const f2 v = (f2){vv.x, vv.y} * cjv;
+            const f2 v = (f2){vv.x, vv.y};
             const f2 w = (f2){ww.x, ww.y};
             f2 b = v * (f2){w.x, w.x};
             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(b) : "v"(v), "v"(w));
@@ -283,17 +319,21 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
             WT_MAC2(SDo, D[7], s20(7 * K)); WT_MAC2(SDo, D[9], s20(9 * K));                                   \
             const f2 Bk = (K & 1) ? Bod : Bev;                                                                \
             const f2 U0 = Bk + (CDe + CDo), V0 = SDe + SDo, U1 = Bk + (CDe - CDo), V1 = SDo - SDe;            \
-            const float r0 = U0.x + V0.y, i0 = U0.y - V0.x, r1 = U1.x + V1.y, i1 = U1.y - V1.x;              \
+            /* X = U - i V (conjugate rows: U + i V): (re, im) = U + sg * (V.y, V.x), one packed fma */            \
+            f2 X0, X1;                                                                                        \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(X0) : "v"(V0), "v"(sg), "v"(U0)); \
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(X1) : "v"(V1), "v"(sg), "v"(U1)); \
             /* |X|^2 directly: torch's stft.abs() ** 2 rounds through a square root, which moves the power by */ \
             /* <= 2 ulp (1e-7 of a log-mel value) and costs an IEEE sqrt per bin */                            \
-            pk2[K] = r0 * r0 + i0 * i0; pk2[10 - K] = r1 * r1 + i1 * i1;                                      \
+            const f2 Q0 = X0 * X0, Q1 = X1 * X1;                                                              \
+            pk2[K] = Q0.x + Q0.y; pk2[10 - K] = Q1.x + Q1.y;                                                  \
         }
         WT_S2(0) WT_S2(1) WT_S2(2) WT_S2(3) WT_S2(4) WT_S2(5)
 #undef WT_S2
 #undef WT_MAC2
 #pragma unroll
-        for (int k2 = 0; k2 < 10; ++k2) pw[slot][u + 20 * k2] = pk2[k2];
-        if (u == 0) pw[slot][200] = pk2[10];   // k = 200 (k1 = 0, k2 = 10)
+        for (int k2 = 0; k2 < 10; ++k2) pw[(u + 20 * k2) * FPB + slot] = pk2[k2];
+        if (u == 0) pw[200 * FPB + slot] = pk2[10];   // k = 200 (k1 = 0, k2 = 10)
     }
     __syncthreads();
 
@@ -305,16 +345,27 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         const int m = o / G, s0 = (o - m * G) * 4;
         if (f0 + s0 >= nvf) continue;
         const int lo = fb_lo[m], n = fb_n[m];
-        const float *w = banded ? fbw + fb_off[m] : fb + m * 201 + lo;  // (global fallback: more than NNZ_CAP taps)
-        const float *p0 = &pw[s0][lo], *p1 = &pw[s0 + 1][lo], *p2 = &pw[s0 + 2][lo], *p3 = &pw[s0 + 3][lo];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int k = 0; k < n; ++k) {
-            const float wk = w[k];
-            a0 = fmaf(wk, p0[k], a0);
-            a1 = fmaf(wk, p1[k], a1);
-            a2 = fmaf(wk, p2[k], a2);
-            a3 = fmaf(wk, p3[k], a3);
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const float4 *pp = reinterpret_cast<const float4 *>(pw + lo * FPB + s0);   // [tap k] at pp[3 * k] (FPB = 12 floats per bin)
+        f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        if (banded) {
+            const float *w = fbw + fb_off[m];
+            for (int k = 0; k < n; ++k) {
+                const float wk = w[k];
+                const float4 p = pp[3 * k];
+                a01 = __builtin_elementwise_fma((f2){p.x, p.y}, (f2){wk, wk}, a01);
+                a23 = __builtin_elementwise_fma((f2){p.z, p.w}, (f2){wk, wk}, a23);
+            }
+        } else {                                   // more than NNZ_CAP taps: the weights stay in global memory
+            const float *w = fb + m * 201 + lo;
+            for (int k = 0; k < n; ++k) {
+                const float wk = w[k];
+                const float4 p = pp[3 * k];
+                a01 = __builtin_elementwise_fma((f2){p.x, p.y}, (f2){wk, wk}, a01);
+                a23 = __builtin_elementwise_fma((f2){p.z, p.w}, (f2){wk, wk}, a23);
+            }
         }
+        const float a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
         // log10 on v_log_f32 (log2, ~1 ulp) * log10(2): |error| < 3e-7 on values in [-10, 5]; ocml's log10f is 25 VALU
         const float L2 = 0.30102999566398120f;
         const float v0 = __builtin_amdgcn_logf(fmaxf(a0, 1e-10f)) * L2, v1 = __builtin_amdgcn_logf(fmaxf(a1, 1e-10f)) * L2;
@@ -372,7 +423,8 @@ static int upload_tables(hipStream_t st) {
     for (int n = 0; n < 400; ++n) {
         hann[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / 400.0));
         const int e = (n / 20) * (n % 20);   // n = 20*n2 + k1 -> exponent n2*k1 (<= 361)
-        w400[n] = make_float2((float)std::cos(2.0 * PI * e / 400.0), (float)std::sin(2.0 * PI * e / 400.0));
+        const double sgn = (n % 20) > 10 ? -1.0 : 1.0;   // rows k1 > 10 use the conjugate twiddle (see stage 2)
+        w400[n] = make_float2((float)std::cos(2.0 * PI * e / 400.0), (float)(sgn * std::sin(2.0 * PI * e / 400.0)));
     }
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_hann), hann, sizeof(hann), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_w400), w400, sizeof(w400), 0, hipMemcpyHostToDevice, st));
