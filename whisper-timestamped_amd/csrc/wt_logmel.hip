@@ -26,6 +26,7 @@
 // zero padding.  Algorithmic bytes: 480000*4 read + n_mels*3000*4 written per
 // chunk (the intermediate is re-read from L2).  The banded form of the
 // filterbank is cached per stream and filterbank pointer.
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 
@@ -132,14 +133,39 @@ __global__ __launch_bounds__(64 * INIT_WAVES) void logmel_init_kernel(int *ws, c
         }
 }
 
+// Persistent: the launch fills the chip once (4 workgroups per CU) and every workgroup walks tiles t, t + gridDim.x, ...
+// (tile = 12 frames of one chunk, numbered chunk * n_wg + index).  The window, twiddle and filterbank tables go to LDS
+// once per workgroup instead of once per tile, and the NEXT tile's PCM span is already travelling (three float4
+// registers per thread, issued right after this tile's span has been published) while this tile is computed: a
+// workgroup never sits through a global-memory latency with its LDS and registers idle.
+struct TileInfo {
+    int chunk, f0, nvs, nvf, i0;
+    bool padding, interior;
+};
+__device__ __forceinline__ TileInfo tile_info(int t, int n_wg, const int32_t *__restrict__ n_valid_samples, int64_t n_samples,
+                                              int n_frames, bool aligned) {
+    TileInfo ti;
+    ti.chunk = t / n_wg;
+    ti.f0 = (t - ti.chunk * n_wg) * FPB;
+    ti.nvs = n_valid_samples ? n_valid_samples[ti.chunk] : (int)n_samples;
+    ti.nvf = min(ti.nvs / 160, n_frames);  // frames kept after dropping the last stft frame
+    ti.padding = ti.f0 >= ti.nvf;          // whole tile is padding
+    ti.i0 = ti.f0 * 160 - 200;             // centre=True: frame f covers padded[160f, 160f+400)
+    // Interior tiles (no reflection at either end of the chunk) are a plain 16-byte-aligned copy: 540 float4 loads
+    // for the workgroup; only the first / last tiles pay for the reflect index arithmetic.
+    ti.interior = !ti.padding && aligned && ti.i0 >= 0 && ti.i0 + SPAN <= ti.nvs;
+    return ti;
+}
+
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__ pcm, int64_t n_samples,
                                                        const int32_t *__restrict__ n_valid_samples,
                                                        const float *__restrict__ fb, const int *__restrict__ ws,
                                                        float *__restrict__ wgmax, int n_mels, int n_frames,
-                                                       float *__restrict__ mel_out) {
+                                                       float *__restrict__ mel_out, int n_wg, int n_tiles) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
     static_assert(FPB * 204 >= SPAN && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
+    static_assert(SPAN % 4 == 0 && SPAN / 4 <= 3 * 256, "three float4 per thread carry a span");
     __shared__ __attribute__((aligned(16))) float span[FPB * 204];
     __shared__ float2 w400[400];
     __shared__ float2 yp[FPB][11][YP];   // stage-1 output, k1 = 0..10 (k1 > 10 is the conjugate of 20-k1)
@@ -150,43 +176,18 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     __shared__ float smax[4];
     float *pw = span;                    // power spectrum, [bin][frame of the tile]: four frames of a bin = one 16-byte read
 
-    const int chunk = blockIdx.y;
-    const int f0 = blockIdx.x * FPB;
-    const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
-    const int nvf = min(nvs / 160, n_frames);  // frames kept after dropping the last stft frame
-    if (f0 >= nvf) {                          // whole tile is padding (block-uniform)
-        if (threadIdx.x == 0) wgmax[(size_t)chunk * gridDim.x + blockIdx.x] = -INFINITY;
-        return;
-    }
-    const float *x = pcm + (int64_t)chunk * n_samples;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int sub = lane / 20;       // frame slot inside the wave (0..2), lanes 60..63 idle
     const int u = lane - sub * 20;   // n2 in stage 1, k1 in stage 2
     const int slot = wave * 3 + sub;
-    const bool act = lane < 60 && (f0 + slot) < nvf;
+    const bool aligned = (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0;
 
-    // ---- phase A: every global read of the tile is issued here, one latency for all of them ----
+    // ---- tables: once per workgroup (published by the first tile's barrier) ----
     const int *g_lo = ws, *g_n = g_lo + MAX_MELS, *g_off = g_n + MAX_MELS, *g_tot = g_off + MAX_MELS;
     const float *g_w = reinterpret_cast<const float *>(g_tot + 1);
     const int nnz = *g_tot;
     const bool banded = nnz <= NNZ_CAP;
-    // PCM span of the tile.  Interior tiles (no reflection at either end of the chunk) are a plain 16-byte-aligned
-    // copy: 540 float4 loads for the workgroup; only the first / last tiles pay for the reflect index arithmetic.
-    const int i0 = f0 * 160 - 200;   // centre=True: frame f covers padded[160f, 160f+400)
-    if (i0 >= 0 && i0 + SPAN <= nvs && (n_samples & 3) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 15) == 0) {  // block-uniform
-        const float4 *src = reinterpret_cast<const float4 *>(x + i0);
-        float4 *dst = reinterpret_cast<float4 *>(span);
-        for (int p = tid; p < SPAN / 4; p += 256) dst[p] = src[p];
-    } else {
-        for (int p = tid; p < SPAN; p += 256) {
-            int i = i0 + p;
-            if (i < 0) i = -i;           // reflect (no edge repeat)
-            if (i >= nvs) i = 2 * (nvs - 1) - i;
-            i = max(0, min(i, nvs - 1));
-            span[p] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
-        }
-    }
     for (int p = tid; p < 400; p += 256) hann[p] = k_hann[p];
     // twiddles laid out [n2][k1] (k_w400 is uploaded in that order): the 20 lanes of a frame read 20 consecutive float2
     // (W400^(n2*k1) indexed by its exponent put up to 10 lanes on one bank pair) at an immediate offset per n2
@@ -194,7 +195,53 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     if (tid < n_mels) { fb_lo[tid] = (unsigned char)g_lo[tid]; fb_n[tid] = (unsigned char)g_n[tid]; fb_off[tid] = (unsigned short)g_off[tid]; }
     if (banded)
         for (int p = tid; p < nnz; p += 256) fbw[p] = g_w[p];
+
+    // the span of an interior tile, in flight: float4 number tid, tid + 256, tid + 512 of its 540
+    float4 pf0 = {0.f, 0.f, 0.f, 0.f}, pf1 = pf0, pf2 = pf0;
+    auto prefetch = [&](const TileInfo &ti) {
+        if (!ti.interior) return;                                // (block-uniform)
+        const float4 *src = reinterpret_cast<const float4 *>(pcm + (int64_t)ti.chunk * n_samples + ti.i0);
+        pf0 = src[tid];
+        pf1 = src[tid + 256];
+        if (tid + 512 < SPAN / 4) pf2 = src[tid + 512];
+    };
+    int t = blockIdx.x;
+    TileInfo cur = {};
+    if (t < n_tiles) {
+        cur = tile_info(t, n_wg, n_valid_samples, n_samples, n_frames, aligned);
+        prefetch(cur);
+    }
+    for (; t < n_tiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    TileInfo nxt = {};
+    if (tn < n_tiles) nxt = tile_info(tn, n_wg, n_valid_samples, n_samples, n_frames, aligned);
+    const int chunk = cur.chunk, f0 = cur.f0, nvs = cur.nvs, nvf = cur.nvf;
+    if (cur.padding) {                        // whole tile is padding (block-uniform)
+        if (tid == 0) wgmax[t] = -INFINITY;
+        prefetch(nxt);
+        cur = nxt;
+        continue;
+    }
+    const bool act = lane < 60 && (f0 + slot) < nvf;
+
+    // ---- phase A: the tile's PCM span into LDS ----
+    if (cur.interior) {
+        float4 *dst = reinterpret_cast<float4 *>(span);
+        dst[tid] = pf0;
+        dst[tid + 256] = pf1;
+        if (tid + 512 < SPAN / 4) dst[tid + 512] = pf2;
+    } else {
+        const float *x = pcm + (int64_t)chunk * n_samples;
+        for (int p = tid; p < SPAN; p += 256) {
+            int i = cur.i0 + p;
+            if (i < 0) i = -i;           // reflect (no edge repeat)
+            if (i >= nvs) i = 2 * (nvs - 1) - i;
+            i = max(0, min(i, nvs - 1));
+            span[p] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
+        }
+    }
     __syncthreads();
+    prefetch(nxt);                            // the next tile's span travels while this one is computed
 
     if (act) {
         // ---- stage 1: radix-20 over n1 for this lane's n2 = u (real input, k1 = 0..10) ----
@@ -381,8 +428,11 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     lmax = wave_max(lmax);
     if (lane == 0) smax[wave] = lmax;
     __syncthreads();
-    // per-workgroup maximum, one slot per workgroup: no atomics, nothing to reset between calls
-    if (tid == 0) wgmax[(size_t)chunk * gridDim.x + blockIdx.x] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    // per-tile maximum, one slot per tile: no atomics, nothing to reset between calls.  (This barrier also ends the
+    // tile's reads of `pw`: the next iteration may overwrite the span.)
+    if (tid == 0) wgmax[t] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    cur = nxt;
+    }   // tiles
 }
 
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const float *__restrict__ wgmax, int n_wg,
@@ -413,6 +463,19 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
 int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared);
 
 static std::mutex g_tables_mu;
+// CUs of the current device (cached per device ordinal; 256 on an MI355X)
+static int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
 static int upload_tables(hipStream_t st) {
     static bool done = false;
     std::lock_guard<std::mutex> lk(g_tables_mu);
@@ -452,8 +515,14 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     // The banded filterbank is cached in the stream's arena: the contents behind `mel_fb` must not change while the
     // same pointer keeps being passed (wt_shutdown() or a different pointer / n_mels rebuilds it).
     if (!prepared) hipLaunchKernelGGL(logmel_init_kernel, dim3(1), dim3(64 * INIT_WAVES), 0, st, ws, mel_fb, n_mels);
-    hipLaunchKernelGGL(stft_mel_kernel, dim3(n_wg, n_chunks), dim3(256), 0, st, pcm, n_samples, n_valid_samples, mel_fb, ws,
-                       wgmax, n_mels, n_frames, mel_out);
+    const long long n_tiles = (long long)n_wg * n_chunks;
+    if (n_tiles > 0x7fffffffLL) {
+        set_error("wt_logmel_batch: too many tiles");
+        return WT_E_UNSUPPORTED;
+    }
+    const int resident = 4 * device_cu_count();   // 39.3 KB of LDS: four workgroups per CU
+    hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)std::min<long long>(n_tiles, resident)), dim3(256), 0, st, pcm, n_samples,
+                       n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_wg, (int)n_tiles);
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, wgmax, n_wg, n_valid_samples,
