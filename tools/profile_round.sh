@@ -3,6 +3,7 @@
 # Produces gpurun_out/<tag>/: bench.json (un-profiled default line, e2e leg and CPU baselines included),
 # kernel_stats.txt (rocprofv3 --kernel-trace of the same kernel-level bench command), traffic.json (FETCH_SIZE /
 # WRITE_SIZE PMC passes, separate runs, gfx950 correction applied, tagged with the workload),
+# sq_counters.txt (SQ instruction / busy / wait / LDS-conflict counters per kernel, two more PMC passes),
 # e2e_kernel_stats.txt (kernel trace of the transcribe()-level leg alone).
 set -u
 tag=${1:-round}
@@ -17,6 +18,10 @@ timeout 600 $B --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- $K --steps 10 --warmup 2 --repeats 5 > "$out/kt.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$out/pmc_write" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_write.log" 2>&1
+# SQ counters of the same command, two passes (instruction mix, busy / wait cycles, LDS bank conflicts per kernel)
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY -d "$out/pmc_sq1" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_sq1.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d "$out/pmc_sq2" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_sq2.log" 2>&1
+python $ROOT/tools/pmc_counters.py $(find "$out/pmc_sq1" "$out/pmc_sq2" -name "*.db") > "$out/sq_counters.txt" 2> "$out/sq_counters.err"
 if [ "$wl" = kfull ]; then
   timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt_e2e" -o kt -- $B --e2e on --no-cpu-baseline --steps 1 --warmup 1 --repeats 1 --e2e-steps 3 > "$out/kt_e2e.log" 2>&1
   ke=$(find "$out/kt_e2e" -name "*.db" | head -1)

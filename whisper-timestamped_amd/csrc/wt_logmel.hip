@@ -58,6 +58,11 @@ __constant__ float2 k_w400[400];  // [n2][k1] = (cos, sin)(2*pi*n2*k1/400): the 
 
 constexpr int FPB = 12;             // frames per workgroup (a multiple of 4: the mel projection reads four frames per tap)
 constexpr int SPAN = 160 * (FPB - 1) + 400;
+// The span sits in LDS with 20 idle floats after every 160 samples: the three frames of a wave then start 180 floats
+// apart (20 mod 32 banks), which makes the stage-1 reads (20 lanes per frame, 32-lane groups on 32 banks)
+// conflict-free; unpadded, frames 0 and 2 of a wave (320 floats apart) sat on the same banks.
+constexpr int SPAD = 20;
+constexpr int SPAN_LDS = SPAN + SPAD * ((SPAN - 1) / 160);
 constexpr int YP = 21;              // padded row of the stage-1 -> stage-2 exchange
 
 __device__ __forceinline__ int enc_key(float v) {
@@ -164,7 +169,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        float *__restrict__ mel_out, int n_wg, int n_tiles) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
-    static_assert(FPB * 204 >= SPAN && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
+    static_assert(FPB * 204 >= SPAN_LDS && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
+    static_assert(SPAD % 4 == 0 && 160 % 4 == 0, "a float4 of the span never straddles a padding gap");
     static_assert(SPAN % 4 == 0 && SPAN / 4 <= 3 * 256, "three float4 per thread carry a span");
     __shared__ __attribute__((aligned(16))) float span[FPB * 204];
     __shared__ float2 w400[400];
@@ -227,9 +233,10 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
     // ---- phase A: the tile's PCM span into LDS ----
     if (cur.interior) {
         float4 *dst = reinterpret_cast<float4 *>(span);
-        dst[tid] = pf0;
-        dst[tid + 256] = pf1;
-        if (tid + 512 < SPAN / 4) dst[tid + 512] = pf2;
+        constexpr int Q = SPAD / 4;               // float4 number p lands at p + Q * (p / 40)
+        dst[tid + Q * (tid / 40)] = pf0;
+        dst[tid + 256 + Q * ((tid + 256) / 40)] = pf1;
+        if (tid + 512 < SPAN / 4) dst[tid + 512 + Q * ((tid + 512) / 40)] = pf2;
     } else {
         const float *x = pcm + (int64_t)chunk * n_samples;
         for (int p = tid; p < SPAN; p += 256) {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
             if (i < 0) i = -i;           // reflect (no edge repeat)
             if (i >= nvs) i = 2 * (nvs - 1) - i;
             i = max(0, min(i, nvs - 1));
-            span[p] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
+            span[p + SPAD * (p / 160)] = x[i];  // plain load: neighbouring tiles re-read 240 of these samples (non-temporal measured +20 %)
         }
     }
     __syncthreads();
@@ -253,24 +260,26 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         typedef float f2 __attribute__((ext_vector_type(2)));
         // The twenty samples and window taps are read as the PAIRS the packed arithmetic wants -- (a[2j-1], a[2j]),
         // (a[21-2j], a[20-2j]), (a0, a9), (a10, a11) -- by ds_read2_b32 with explicit offsets (left to itself hipcc pairs
-        // neighbours (a[2m], a[2m+1]) and spends ~50 v_mov on re-pairing).  Offsets are in dwords (<= 255): second
-        // base at +200 dwords for n1 >= 12.  The compiler does not count these reads: one explicit wait below, tied to
+        // neighbours (a[2m], a[2m+1]) and spends ~50 v_mov on re-pairing).  Offsets are in dwords (<= 255): sample n1
+        // of a frame sits at 20 n1 + 20 (n1 / 8) in the padded span (SPAD), the window tap at 20 n1; second base at
+        // sample 10 for n1 >= 12.  The compiler does not count these reads: one explicit wait below, tied to
         // the destination registers so that nothing that uses them is scheduled above it.
         typedef __attribute__((address_space(3))) const float lds_cf;
-        const unsigned fr0 = (unsigned)(uintptr_t)(lds_cf *)(span + slot * 160 + u), fr1 = fr0 + 800;
+        const unsigned fr0 = (unsigned)(uintptr_t)(lds_cf *)(span + slot * (160 + SPAD) + u), fr1 = fr0 + 4 * (200 + SPAD);
         const unsigned hw0 = (unsigned)(uintptr_t)(lds_cf *)(hann + u), hw1 = hw0 + 800;
         f2 xa[10], xh[10];
 #define WT_RD2(dst, base, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:" #o0 " offset1:" #o1 : "=v"(dst) : "v"(base) : "memory")
+        static_assert(SPAD == 20, "the immediate offsets below are written for SPAD = 20");
         WT_RD2(xa[0], fr0, 20, 40);   WT_RD2(xh[0], hw0, 20, 40);     // U1 = (a1, a2)
-        WT_RD2(xa[1], fr1, 180, 160); WT_RD2(xh[1], hw1, 180, 160);   // V1 = (a19, a18)
+        WT_RD2(xa[1], fr1, 200, 180); WT_RD2(xh[1], hw1, 180, 160);   // V1 = (a19, a18)
         WT_RD2(xa[2], fr0, 60, 80);   WT_RD2(xh[2], hw0, 60, 80);     // U2 = (a3, a4)
-        WT_RD2(xa[3], fr1, 140, 120); WT_RD2(xh[3], hw1, 140, 120);   // V2 = (a17, a16)
+        WT_RD2(xa[3], fr1, 160, 140); WT_RD2(xh[3], hw1, 140, 120);   // V2 = (a17, a16)
         WT_RD2(xa[4], fr0, 100, 120); WT_RD2(xh[4], hw0, 100, 120);   // U3 = (a5, a6)
         WT_RD2(xa[5], fr1, 100, 80);  WT_RD2(xh[5], hw1, 100, 80);    // V3 = (a15, a14)
-        WT_RD2(xa[6], fr0, 140, 160); WT_RD2(xh[6], hw0, 140, 160);   // U4 = (a7, a8)
+        WT_RD2(xa[6], fr0, 140, 180); WT_RD2(xh[6], hw0, 140, 160);   // U4 = (a7, a8)
         WT_RD2(xa[7], fr1, 60, 40);   WT_RD2(xh[7], hw1, 60, 40);     // V4 = (a13, a12)
-        WT_RD2(xa[8], fr0, 0, 180);   WT_RD2(xh[8], hw0, 0, 180);     // (a0, a9)
-        WT_RD2(xa[9], fr0, 200, 220); WT_RD2(xh[9], hw0, 200, 220);   // (a10, a11)
+        WT_RD2(xa[8], fr0, 0, 200);   WT_RD2(xh[8], hw0, 0, 180);     // (a0, a9)
+        WT_RD2(xa[9], fr0, 220, 240); WT_RD2(xh[9], hw0, 200, 220);   // (a10, a11)
 #undef WT_RD2
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]),
@@ -324,12 +333,13 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         const float2 *wrow = w400 + u;
 #pragma unroll
         for (int n2 = 0; n2 < 20; ++n2) {
-            const float2 vv = yp[slot][ks][n2];
-            const float2 ww = wrow[20 * n2];  // (cos, +-sin) of W400^(n2*u)
+            // volatile: keeps these forty reads as forty ds_read_b64 (2 LDS cycles each, 64 banks, conflict-free with
+            // this layout); merged into ds_read2_b64 by the compiler they cost 8 cycles a pair on 32 banks
+            typedef __attribute__((address_space(3))) const volatile f2 lds_vf2;
+            const f2 v = *(lds_vf2 *)(&yp[slot][ks][n2]);
+            const f2 w = *(lds_vf2 *)(&wrow[20 * n2]);  // (cos, +-sin) of W400^(n2*u)
             // (re + i im)(cos - i sin) = cos*(re, im) + sin*(im, -re): one packed multiply + one packed fma whose
             // operand modifiers do the swap and the sign (hipcc spends a v_xor and a v_mov on them)
-            const f2 v = (f2){vv.x, vv.y};
-            const f2 w = (f2){ww.x, ww.y};
             f2 b = v * (f2){w.x, w.x};
             asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "+v"(b) : "v"(v), "v"(w));
             B[n2] = b;
