@@ -12,16 +12,18 @@
 // 20*n1 + n2, k = k1 + 20*k2).  Twenty lanes own one frame; each lane does a
 // radix-20 butterfly entirely in registers; both stages pair n with 20-n and
 // k with 10-k, and the 20th roots of unity are compile-time constants, so the
-// zeros and +-1 fold away: 324 multiply-adds per lane instead of 1240.  The
-// W400 twiddle comes from a 3.2 KB LDS table laid out [n2][k1], the transposition between the
-// two stages goes through LDS.  Three frames per wave, twelve per 256-thread
-// workgroup (39 KB of LDS: 16 waves per CU), 250 workgroups per 30 s chunk.
-// ~13 kFLOP per frame instead of 322 kFLOP for the direct DFT.  What bounds it
-// (profiles/r2b_logmel_sq_counters.txt): the two instruction streams themselves -- VALU busy 62 % of the kernel
-// (each wave64 VALU instruction of this mix holds its SIMD for 4 cycles), LDS array busy 55 % (a third of it bank
-// conflicts, measured before the [n2][k1] twiddle table) -- not the synchronisation: a persistent,
-// barrier-free, wave-autonomous variant (tools/probes/stft_mel_wave_variant.hip) measured 63 us against 60.
-// Pass 1 writes log10(mel) and one maximum per workgroup (no atomics, nothing
+// zeros and +-1 fold away: 324 multiply-adds per lane instead of 1240, carried
+// two per instruction (v_pk_*_f32).  The W400 twiddle comes from a 3.2 KB LDS
+// table laid out [n2][k1], the transposition between the two stages goes
+// through LDS.  Three frames per wave, twelve per 256-thread workgroup (a tile;
+// 39 KB of LDS: 16 waves per CU), 250 tiles per 30 s chunk, walked by a
+// persistent grid of four workgroups per CU that keeps its tables in LDS and
+// prefetches the next tile's samples.  ~13 kFLOP per frame instead of 322 kFLOP
+// for the direct DFT.  What bounds it (profiles/r2l_sq_counters.txt, DESIGN.md
+// section 6): the VALU and LDS instruction streams of four waves per SIMD, about
+// half of the kernel each; the LDS instruction forms are chosen by their gfx950
+// cost (single ds_read_b64 on 64 banks, 32-bank dword reads on a padded span).
+// Pass 1 writes log10(mel) and one maximum per tile (no atomics, nothing
 // to reset); pass 2 reduces them per chunk, applies the clamp/scale and the
 // zero padding.  Algorithmic bytes: 480000*4 read + n_mels*3000*4 written per
 // chunk (the intermediate is re-read from L2).  The banded form of the
