@@ -565,6 +565,43 @@ def test_logmel_vs_oracle():
         assert L.find_start_padding(mel.to(DEV)).cpu().tolist()[2] == valid[2] // 160
 
 
+def test_logmel_batch_walks_tiles():
+    """The STFT kernel is persistent: with more tiles than resident workgroups (4 per CU) a workgroup walks several
+    tiles, prefetching the next span while it computes.  A ragged batch (full, short, tile-boundary and nearly empty
+    chunks in every order, so that interior, reflecting and all-padding tiles follow each other) must give, chunk by
+    chunk, exactly what the one-chunk call gives (one tile per workgroup, nothing prefetched across tiles) -- also with
+    sample counts that are not a multiple of 4 and a base pointer that is not 16-byte aligned (scalar span loads)."""
+    L = _lib()
+    rng = np.random.RandomState(11)
+    n = 480000
+    lengths = [n, 160 * 12 * 7, 201, n - 1, 16000 * 11 + 3, 160 * 12 * 100 + 5, 399, n, 160 * 1500, 1000, n - 160 * 12, 16000 * 29]
+    lengths = lengths + lengths[::-1]                              # 24 chunks x 250 tiles: ~6 tiles per workgroup
+    pcm = (0.1 * rng.standard_normal((len(lengths), n))).astype(np.float32)
+    for b, m in enumerate(lengths):
+        pcm[b, m:] = 0.0
+    valid = torch.tensor(lengths, dtype=torch.int32)
+    fb = O.mel_filters_ref(80)
+    dev_pcm = torch.from_numpy(pcm).to(DEV)
+    mel, gmax = L.logmel(dev_pcm, fb, valid)
+    for b, m in enumerate(lengths):
+        one, g1 = L.logmel(dev_pcm[b:b + 1], fb, valid[b:b + 1])
+        assert torch.equal(mel[b], one[0]), (b, m)
+        assert torch.equal(gmax[b], g1[0]), (b, m)
+    for b in (0, 2, 4, 5):                                         # and the oracle on a few of them
+        ref = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(torch.from_numpy(pcm[b, :lengths[b]]), 80), 3000)
+        assert (mel[b].cpu() - ref).abs().max().item() < 2e-4, b
+    # scalar span loads: rows of n - 2 samples carved out of a buffer one float off a 16-byte boundary
+    flat = torch.zeros(len(lengths) * (n - 2) + 1, dtype=torch.float32, device=DEV)
+    odd = flat[1:].view(len(lengths), n - 2)
+    odd.copy_(dev_pcm[:, :n - 2])
+    assert odd.data_ptr() % 16 == 4
+    v2 = torch.clamp(valid, max=n - 2)
+    mel2, _ = L.logmel(odd, fb, v2)
+    for b in (0, 1, 3, 7):
+        one, _ = L.logmel(dev_pcm[b:b + 1, :n - 2].contiguous(), fb, v2[b:b + 1])
+        assert torch.equal(mel2[b], one[0]), b
+
+
 def test_reference_side_stub():
     """Executes the ctypes stub printed in INTEGRATION.md section 3 (what a maintainer of the reference would
     add) against the oracle, so the documented binding cannot rot."""
