@@ -213,16 +213,24 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
         pf1 = src[tid + 256];
         if (tid + 512 < SPAN / 4) pf2 = src[tid + 512];
     };
-    int t = blockIdx.x;
+    // XCD-aware walk: workgroups are dealt to the 8 XCDs round-robin (workgroup b -> XCD b % 8, each with its own L2), so
+    // XCD x owns the CONTIGUOUS tile range [x N / 8, (x + 1) N / 8) and its workgroups take neighbouring tiles at the
+    // same time: the 240 samples two neighbouring tiles share and the 48-byte pieces they write into the same
+    // 128-byte lines of a mel row then meet in ONE L2 instead of travelling to HBM from two.
+    const int XCDS = min(8, (int)gridDim.x);   // (fewer workgroups than XCDs: one range per workgroup)
+    const int xcd = blockIdx.x % XCDS, rank_in_xcd = blockIdx.x / XCDS;
+    const int wgs_in_xcd = ((int)gridDim.x - xcd + XCDS - 1) / XCDS;
+    const int t_hi = (int)(((long long)(xcd + 1) * n_tiles) / XCDS);
+    int t = (int)(((long long)xcd * n_tiles) / XCDS) + rank_in_xcd;
     TileInfo cur = {};
-    if (t < n_tiles) {
+    if (t < t_hi) {
         cur = tile_info(t, n_wg, n_valid_samples, n_samples, n_frames, aligned);
         prefetch(cur);
     }
-    for (; t < n_tiles; t += gridDim.x) {
-    const int tn = t + gridDim.x;
+    for (; t < t_hi; t += wgs_in_xcd) {
+    const int tn = t + wgs_in_xcd;
     TileInfo nxt = {};
-    if (tn < n_tiles) nxt = tile_info(tn, n_wg, n_valid_samples, n_samples, n_frames, aligned);
+    if (tn < t_hi) nxt = tile_info(tn, n_wg, n_valid_samples, n_samples, n_frames, aligned);
     const int chunk = cur.chunk, f0 = cur.f0, nvs = cur.nvs, nvf = cur.nvf;
     if (cur.padding) {                        // whole tile is padding (block-uniform)
         if (tid == 0) wgmax[t] = -INFINITY;
