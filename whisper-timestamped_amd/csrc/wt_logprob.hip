@@ -65,8 +65,12 @@ __global__ __launch_bounds__(256) void logprob_gather_kernel(const LT *__restric
     MS acc = {-INFINITY, 0.f};
 
     constexpr int VEC = 16 / sizeof(LT);  // elements per 16-byte load
+    // The vector stream starts on a 128-BYTE boundary (not merely a 16-byte one): a wave's 64 x 16-byte request is
+    // then exactly eight cache lines.  Started on an arbitrary 16-byte boundary it straddles nine, and the line it
+    // shares with the neighbouring wave is fetched twice -- the stream is non-temporal, nothing keeps it in L2 --
+    // which was 6.5 % more HBM bytes than the rows hold (FETCH_SIZE: 1583 MB for 1487 MB of logits).
     const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
-    int head = (int)(((16 - (addr & 15)) & 15) / sizeof(LT));
+    int head = (int)(((128 - (addr & 127)) & 127) / sizeof(LT));   // <= 31 (fp32) / 63 (fp16) elements: one per thread
     if (head > V) head = V;
     const int nvec = (V - head) / VEC;
     const int tail0 = head + nvec * VEC;
