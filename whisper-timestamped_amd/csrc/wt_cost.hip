@@ -224,16 +224,25 @@ constexpr int CN_WAVES = 16;
 constexpr int CN_ROWS = (WT_MAX_TOKENS + CN_WAVES - 1) / CN_WAVES;
 __global__ __launch_bounds__(64 * CN_WAVES) void colnorm_kernel(float *__restrict__ cost,
                                                                 const wt_seg_desc *__restrict__ segs,
-                                                                unsigned *__restrict__ segmax, int unit0) {
-    const int unit = unit0 + blockIdx.y;
+                                                                unsigned *__restrict__ segmax, int unit0, int n_units) {
+    // XCD-aware: workgroups go to the 8 XCDs round-robin in linear order (id = x + gridDim.x * y -> XCD id % 8).  A row of
+    // the cost matrix is F * 4 bytes, not a multiple of 128: the 256-byte row segments of neighbouring column blocks
+    // share a cache line, so ALL column blocks of a unit are given to ONE XCD (unit u -> XCD u % 8) and meet in its L2
+    // instead of each fetching the shared line from HBM.  The launch pads gridDim.y to a multiple of 8.
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int q = lin >> 3;
+    const int col_block = q % (int)gridDim.x;
+    const int local_unit = 8 * (q / (int)gridDim.x) + (lin & 7);
+    if (local_unit >= n_units) return;      // block-uniform (padding of the grid)
+    const int unit = unit0 + local_unit;
     const wt_seg_desc d = segs[unit];
     const int F = d.F, T = d.T;
-    if ((int)blockIdx.x * 64 >= F) return;  // block-uniform
+    if (col_block * 64 >= F) return;  // block-uniform
     __shared__ double ssq[CN_WAVES][64];
     __shared__ float smx[CN_WAVES][64];
     __shared__ float snorm[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int f = blockIdx.x * 64 + lane;
+    const int f = col_block * 64 + lane;
     const bool valid = f < F;
     const bool masked_col = d.pad_from > 0 && f >= d.pad_from;  // 0 = no mask, like the reference's `if max_duration:`
     float *base = cost + d.cost_offset + (valid ? f : 0);
@@ -429,11 +438,11 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     if (rc) return rc;
     if (grouped) {
         for (int k = 0; k < n_groups; ++k)
-            hipLaunchKernelGGL(colnorm_kernel, dim3((groups[k].maxF + 63) / 64, groups[k].n), dim3(64 * CN_WAVES), 0, st, cost,
-                               segs_dev, segstate, groups[k].lo);
+            hipLaunchKernelGGL(colnorm_kernel, dim3((groups[k].maxF + 63) / 64, (groups[k].n + 7) & ~7), dim3(64 * CN_WAVES), 0, st,
+                               cost, segs_dev, segstate, groups[k].lo, groups[k].n);
     } else {
-        hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, n_seg), dim3(64 * CN_WAVES), 0, st, cost, segs_dev, segstate,
-                           0);
+        hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, (n_seg + 7) & ~7), dim3(64 * CN_WAVES), 0, st, cost, segs_dev,
+                           segstate, 0, n_seg);
     }
     hipLaunchKernelGGL(fix00_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, st, cost, segs_dev, segstate, n_seg);
     WT_HIP(hipGetLastError());
