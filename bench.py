@@ -446,17 +446,19 @@ def run_e2e(dev, args, rank, world, dist):
     from whisper_timestamped.alignment import head_pairs
     from whisper_timestamped.batched import BatchedAligner, WindowJob, align_windows
     from whisper_timestamped.transcribe import get_alignment_heads
-    n_per, steps = 32, args.e2e_steps
-    model = W.build_model("base", seed=0, device=dev)
+    n_per, steps = args.e2e_windows, args.e2e_steps
+    name = args.e2e_model
+    model = W.build_model(name, seed=0, device=dev)
     if hasattr(model, "alignment_heads"):
         del model.alignment_heads                          # -> the published whisper-base heads (parameter-count table)
     heads = head_pairs(get_alignment_heads(model))
-    tokenizer = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    tokenizer = W.tokenizer.get_tokenizer(True, language="en", task="transcribe",
+                                          **({"num_languages": 100} if model.dims.n_vocab >= 51866 else {}))
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
     pcm = torch.randn((n_per, 480000), generator=g, device=dev) * 0.1
     transcripts = [e2e_transcript(tokenizer, 100 + k) for k in range(n_per)]
     jobs = [WindowJob(pcm[k % n_per], transcripts[k % n_per], 480000, tag=k) for k in range(n_per * steps)]
-    out = {"workload": f"whisper-base (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
+    out = {"workload": f"whisper-{name} (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
                        f"{len(transcripts[0])} window tokens in {len(E2E_SEGMENTS)} timestamped segments, teacher forced "
                        f"(naive strategy, trust_whisper_timestamps=False shape)", "chunks_per_launch": n_per,
            "launch_sets": steps, "alignment_heads": len(heads)}
@@ -521,7 +523,7 @@ def run_e2e(dev, args, rank, world, dist):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same chunks through the reference-shaped CPU path, bounded sample
-        model_cpu = W.build_model("base", seed=0, device="cpu")
+        model_cpu = W.build_model(name, seed=0, device="cpu")
         pcm_cpu = pcm[:8].cpu()
         done, worst_t, worst_c, t0 = 0, 0.0, 0.0, time.perf_counter()
         while done < 8:
@@ -562,6 +564,9 @@ def main():
     ap.add_argument("--e2e", default="auto", choices=["auto", "on", "off"],
                     help="transcribe()-level leg (whisper-base, batched.py); auto = with the default workload")
     ap.add_argument("--e2e-steps", type=int, default=6, help="launch sets of 32 chunks in the e2e timed region")
+    ap.add_argument("--e2e-model", default="base", help="shapes of the e2e leg's model (whisper_double names: base = the "
+                                                         "BASELINE config; small, medium, large-v3 ... for other shapes)")
+    ap.add_argument("--e2e-windows", type=int, default=32, help="30 s chunks per launch set of the e2e leg")
     ap.add_argument("--e2e-cpu-budget", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as ONE captured HIP graph (fixed shapes); stage times then come from an eager "
