@@ -471,11 +471,27 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
     const float floor_v = mx - 8.0f;
     float *base = mel_out + (int64_t)chunk * n_mels * n_frames;
     const int total = n_mels * n_frames;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int fr = e % n_frames;
-        float v = 0.f;  // pad_or_trim: exact zeros
-        if (fr < nvf) v = (fmaxf(base[e], floor_v) + 4.0f) / 4.0f;
-        base[e] = v;
+    if ((n_frames & 3) == 0 && (reinterpret_cast<uintptr_t>(mel_out) & 15) == 0) {   // block-uniform: 16 bytes per thread
+        float4 *base4 = reinterpret_cast<float4 *>(base);                             // (a row is a whole number of float4)
+        for (int e4 = blockIdx.x * 256 + threadIdx.x; e4 < total / 4; e4 += gridDim.x * 256) {
+            const int fr = (e4 * 4) % n_frames;
+            float4 v = {0.f, 0.f, 0.f, 0.f};  // pad_or_trim: exact zeros
+            if (fr < nvf) {
+                const float4 x = base4[e4];
+                v.x = (fmaxf(x.x, floor_v) + 4.0f) / 4.0f;
+                if (fr + 1 < nvf) v.y = (fmaxf(x.y, floor_v) + 4.0f) / 4.0f;
+                if (fr + 2 < nvf) v.z = (fmaxf(x.z, floor_v) + 4.0f) / 4.0f;
+                if (fr + 3 < nvf) v.w = (fmaxf(x.w, floor_v) + 4.0f) / 4.0f;
+            }
+            base4[e4] = v;
+        }
+    } else {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int fr = e % n_frames;
+            float v = 0.f;  // pad_or_trim: exact zeros
+            if (fr < nvf) v = (fmaxf(base[e], floor_v) + 4.0f) / 4.0f;
+            base[e] = v;
+        }
     }
     if (gmax && blockIdx.x == 0 && threadIdx.x == 0) gmax[chunk] = mx;
 }
