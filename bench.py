@@ -796,7 +796,7 @@ def main():
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph), "batches_in_flight": args.pipeline,
-                       "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if world > 1 else "none"},
+                       "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if gatherers is not None else "none"},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region",
                        "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
                        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
