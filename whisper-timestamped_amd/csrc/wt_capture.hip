@@ -171,15 +171,17 @@ __global__ __launch_bounds__(256) void qk_rows_batch_kernel(QkLayers L, int n_q,
         }
         __syncthreads();
         for (int r = 0; r < nr; ++r) {
-            float acc = 0.f;
+            // 64 multiply-adds as 32 v_pk_fma_f32 on two independent accumulator pairs (dimensions 4j, 4j+1 | 4j+2,
+            // 4j+3): half the VALU instructions of the scalar chain and two chains in flight per lane
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 acc_a = {0.f, 0.f}, acc_b = {0.f, 0.f};
 #pragma unroll
             for (int d = 0; d < HD; d += 4) {
                 const float4 qv = *reinterpret_cast<const float4 *>(&qs[r][d]);
-                acc = fmaf(qv.x, kr[d], acc);
-                acc = fmaf(qv.y, kr[d + 1], acc);
-                acc = fmaf(qv.z, kr[d + 2], acc);
-                acc = fmaf(qv.w, kr[d + 3], acc);
+                acc_a = __builtin_elementwise_fma((f2){qv.x, qv.y}, (f2){kr[d], kr[d + 1]}, acc_a);
+                acc_b = __builtin_elementwise_fma((f2){qv.z, qv.w}, (f2){kr[d + 2], kr[d + 3]}, acc_b);
             }
+            float acc = (acc_a.x + acc_a.y) + (acc_b.x + acc_b.y);
             if (sizeof(T) == 2) acc = __half2float(__float2half(acc));
             if (f_ok) out[(int64_t)(r0 + r) * n_ctx] = cvt<float, DT>(acc);
         }
