@@ -34,6 +34,12 @@ decoder (fixed synthetic transcript) -> wt_qk_rows_batch -> ONE wt_align_batch
 the share of the alignment kernels in the GPU time and the same chunks through
 the reference-shaped CPU path (oracle/, same model on the CPU) beside it.
 
+Process structure: the process the driver starts is an orchestrator that never touches the GPU.  The kernel-level
+measurement, the CPU baselines and each transcribe()-level leg run in CHILD processes of this script which publish
+their results as they go (the single-stream line before the multi-stream pass starts, the fp32 e2e leg before the
+half-precision ones ...): a GPU fault in any leg costs that leg -- reported as {"error": "signal 6"} -- not the line.
+`python bench.py --gpus N` outside a launcher re-executes itself under torch.distributed.run (one rank per GPU).
+
 Prints ONE JSON line (rank 0).  metric = audio-seconds aligned per second.
 """
 import argparse
@@ -438,9 +444,12 @@ def e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm, window_tokens)
     return ws
 
 
-def run_e2e(dev, args, rank, world, dist):
+def run_e2e(dev, args, leg, emit):
     """audio-seconds transcribed-with-word-timestamps per second at the transcribe() level (SURVEY 8d "End-to-end
-    audio-s/s"): whisper-base, 32 synthetic 30 s chunks per launch set, teacher-forced transcript."""
+    audio-s/s"): whisper-base, 32 synthetic 30 s chunks per launch set, teacher-forced transcript.  One leg per child
+    process: "fp32" (the CPU reference's arithmetic; also the CPU e2e baseline and the word parity against it) or
+    "fp16" (half-precision activations, eager, then the forward pass as one captured HIP graph).  `emit` publishes
+    what has been measured so far: a fault later in the leg cannot take it back."""
     import whisper_double as W          # tests/whisper_double: stand-in for openai-whisper (absent from this image)
     W.install()
     from whisper_timestamped.alignment import head_pairs
@@ -454,31 +463,20 @@ def run_e2e(dev, args, rank, world, dist):
     heads = head_pairs(get_alignment_heads(model))
     tokenizer = W.tokenizer.get_tokenizer(True, language="en", task="transcribe",
                                           **({"num_languages": 100} if model.dims.n_vocab >= 51866 else {}))
-    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    g = torch.Generator(device=dev).manual_seed(4321)
     pcm = torch.randn((n_per, 480000), generator=g, device=dev) * 0.1
     transcripts = [e2e_transcript(tokenizer, 100 + k) for k in range(n_per)]
     jobs = [WindowJob(pcm[k % n_per], transcripts[k % n_per], 480000, tag=k) for k in range(n_per * steps)]
-    out = {"workload": f"whisper-{name} (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
-                       f"{len(transcripts[0])} window tokens in {len(E2E_SEGMENTS)} timestamped segments, teacher forced "
-                       f"(naive strategy, trust_whisper_timestamps=False shape)", "chunks_per_launch": n_per,
-           "launch_sets": steps, "alignment_heads": len(heads)}
+    out = {}
 
-    def timed(aligner, label):
+    def timed(aligner):
         list(align_windows(aligner, jobs[:n_per], n_per))                    # warm-up (allocations, GEMM plans)
         torch.cuda.synchronize()
         aligner.timeline = []
-        if dist is not None:
-            dist.barrier()
         t0 = time.perf_counter()
         res = list(align_windows(aligner, jobs, n_per))
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
         el = time.perf_counter() - t0
-        if dist is not None:
-            te = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            el = float(te.item())
         tl = aligner.timeline
         aligner.timeline = None
         stage = {k: float(np.mean([t[k] for t in tl])) for k in tl[0]} if tl else {}
@@ -487,69 +485,72 @@ def run_e2e(dev, args, rank, world, dist):
         align_ms = sum(v for k, v in stage.items() if k != "model")
         n_words = sum(len(r.words) for r in res)
         assert all(len(r.words) > 0 for r in res) and n_words > 0
-        return res, {"audio_s_per_s": round(world * 30.0 * len(jobs) / el, 1), "ms_per_launch_set": round(el / steps * 1e3, 3),
+        return res, {"audio_s_per_s": round(30.0 * len(jobs) / el, 1), "ms_per_launch_set": round(el / steps * 1e3, 3),
                      "gpu_kernel_ms_per_launch_set": round(gpu_ms, 3),
                      "gpu_stage_ms": {k: round(v, 3) for k, v in stage.items()},
-                     "alignment_share": round(align_ms / gpu_ms, 4) if gpu_ms else None,      # of the GPU kernel time
                      "alignment_share_of_gpu_time": round(align_ms / gpu_ms, 4) if gpu_ms else None,
                      "gpu_span_ms_per_launch_set": round(span_ms, 3),
                      "gpu_busy_fraction_of_wall": round(min(1.0, gpu_ms * steps / (el * 1e3)), 4),
                      "words_per_launch_set": n_words // steps}
 
     opts = dict(language="en", alignment_heads=torch.tensor(heads), refine_whisper_precision_nframes=25)
-    aligner = BatchedAligner(model, tokenizer, **opts)
-    res32, fp32 = timed(aligner, "fp32")
-    out.update(fp32)
-    out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
+    if leg == "fp32":
+        out = {"workload": f"whisper-{name} (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
+                           f"{len(transcripts[0])} window tokens in {len(E2E_SEGMENTS)} timestamped segments, teacher forced "
+                           f"(naive strategy, trust_whisper_timestamps=False shape)", "chunks_per_launch": n_per,
+               "launch_sets": steps, "alignment_heads": len(heads)}
+        res32, fp32 = timed(BatchedAligner(model, tokenizer, **opts))
+        out.update(fp32)
+        out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
+        emit(out)
+        if not args.no_cpu_baseline:
+            # the same chunks through the reference-shaped CPU path, bounded sample
+            model_cpu = W.build_model(name, seed=0, device="cpu")
+            pcm_cpu = pcm[:8].cpu()
+            done, worst_t, worst_c, t0 = 0, 0.0, 0.0, time.perf_counter()
+            while done < 8:
+                ws = e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm_cpu[done], transcripts[done])
+                got = res32[done]
+                assert [x["text"] for x in got.words] == [x["text"] for x in ws], "GPU and CPU words differ"
+                for a, lp, b in zip(got.words, got.word_logprobs, ws):
+                    worst_t = max(worst_t, abs(a["start"] - b["start"]), abs(a["end"] - b["end"]))
+                    conf = lp.mean().exp().item() if len(lp) else 0.0
+                    worst_c = max(worst_c, abs(conf - b["confidence_raw"]))
+                done += 1
+                if time.perf_counter() - t0 > args.e2e_cpu_budget:
+                    break
+            el = time.perf_counter() - t0
+            out["cpu_baseline_e2e"] = {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s",
+                                       "cores": int(torch.get_num_threads()), "kind": "port",
+                                       "sample": f"{done} of the same chunks, one at a time as the reference does: torch.stft log-mel, "
+                                                 f"the same whisper-base on the CPU with unfused attention and per-layer QK capture, "
+                                                 f"log_softmax of the (T, V) block, oracle perform_word_alignment, {el:.1f} s wall"}
+            out["parity_vs_cpu_reference_path"] = {"chunks": done, "max_abs_dt_word_s": round(worst_t, 4),
+                                                   "max_abs_dconfidence_before_rounding": float(f"{worst_c:.3g}")}
+            out["speedup_vs_cpu_e2e"] = round(out["audio_s_per_s"] / out["cpu_baseline_e2e"]["value"], 1)
+            emit(out)
+        return out
     # the reference's GPU default is fp16=True (transcribe.py:240-241): the same pipeline with half-precision
     # activations -- whisper keeps LayerNorm in fp32 and casts the other weights per call; here they are cast once.
-    # These two legs are extras: a failure in them is reported in the line instead of costing the line.
-    try:
-        for m in model.modules():
-            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
-                m.half()
-        res16, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts), "fp16")
-        out["fp16_model"] = fp16
-        # ... and with the forward pass replayed as ONE captured HIP graph (the eager half-precision pass is bound by
-        # the Python dispatch of ~300 small launches, not by the GPU)
-        res_g, fp16g = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, forward_graph=True, **opts), "fp16 graph")
-        fp16g["words_equal_the_eager_pass"] = all(
-            [w["text"] for w in a.words] == [w["text"] for w in b.words] and
-            all(abs(x["start"] - y["start"]) <= 0.02 and abs(x["end"] - y["end"]) <= 0.02 for x, y in zip(a.words, b.words))
-            for a, b in zip(res_g, res16))
-        out["fp16_model_forward_as_hip_graph"] = fp16g
-    except Exception as err:  # noqa: BLE001
-        out["fp16_legs_error"] = f"{type(err).__name__}: {err}"[:300]
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the same chunks through the reference-shaped CPU path, bounded sample
-        model_cpu = W.build_model(name, seed=0, device="cpu")
-        pcm_cpu = pcm[:8].cpu()
-        done, worst_t, worst_c, t0 = 0, 0.0, 0.0, time.perf_counter()
-        while done < 8:
-            ws = e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm_cpu[done], transcripts[done])
-            got = res32[done]
-            assert [x["text"] for x in got.words] == [x["text"] for x in ws], "GPU and CPU words differ"
-            for a, lp, b in zip(got.words, got.word_logprobs, ws):
-                worst_t = max(worst_t, abs(a["start"] - b["start"]), abs(a["end"] - b["end"]))
-                conf = lp.mean().exp().item() if len(lp) else 0.0
-                worst_c = max(worst_c, abs(conf - b["confidence_raw"]))
-            done += 1
-            if time.perf_counter() - t0 > args.e2e_cpu_budget:
-                break
-        el = time.perf_counter() - t0
-        out["cpu_baseline_e2e"] = {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s",
-                                   "cores": int(torch.get_num_threads()), "kind": "port",
-                                   "sample": f"{done} of the same chunks, one at a time as the reference does: torch.stft log-mel, "
-                                             f"the same whisper-base on the CPU with unfused attention and per-layer QK capture, "
-                                             f"log_softmax of the (T, V) block, oracle perform_word_alignment, {el:.1f} s wall"}
-        out["parity_vs_cpu_reference_path"] = {"chunks": done, "max_abs_dt_word_s": round(worst_t, 4),
-                                               "max_abs_dconfidence_before_rounding": float(f"{worst_c:.3g}")}
-        out["speedup_vs_cpu_e2e"] = round(out["audio_s_per_s"] / out["cpu_baseline_e2e"]["value"], 1)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Embedding)):
+            m.half()
+    res16, fp16 = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, **opts))
+    out["fp16_model"] = fp16
+    emit(out)
+    # ... and with the forward pass replayed as ONE captured HIP graph (the eager half-precision pass is bound by
+    # the Python dispatch of ~300 small launches, not by the GPU)
+    res_g, fp16g = timed(BatchedAligner(model, tokenizer, mel_dtype=torch.float16, forward_graph=True, **opts))
+    fp16g["words_equal_the_eager_pass"] = all(
+        [w["text"] for w in a.words] == [w["text"] for w in b.words] and
+        all(abs(x["start"] - y["start"]) <= 0.02 and abs(x["end"] - y["end"]) <= 0.02 for x, y in zip(a.words, b.words))
+        for a, b in zip(res_g, res16))
+    out["fp16_model_forward_as_hip_graph"] = fp16g
+    emit(out)
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -562,7 +563,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="fixed number of timed regions (0 = from --min-seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", default="auto", choices=["auto", "on", "off"],
-                    help="transcribe()-level leg (whisper-base, batched.py); auto = with the default workload")
+                    help="transcribe()-level legs (whisper-base, batched.py); auto = with the default workload at N=1")
     ap.add_argument("--e2e-steps", type=int, default=6, help="launch sets of 32 chunks in the e2e timed region")
     ap.add_argument("--e2e-model", default="base", help="shapes of the e2e leg's model (whisper_double names: base = the "
                                                          "BASELINE config; small, medium, large-v3 ... for other shapes)")
@@ -582,36 +583,73 @@ def main():
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel", "cumask"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
-    args = ap.parse_args()
+    # --- process plumbing (see orchestrate()): the measuring legs run in child processes of this script
+    ap.add_argument("--role", default="orchestrate", choices=["orchestrate", "kernel", "cpu", "e2e"], help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16"], help=argparse.SUPPRESS)
+    ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (gloo on the CPU, no kernels, meaningless numbers): what "
+                         "tests/test_bench_launcher.py runs where there is no GPU")
+    ap.add_argument("--inject-fault", default="", help=argparse.SUPPRESS)   # tests: "kernel", "e2e_fp16" ... abort that child
+    args = ap.parse_args(argv)
+    if args.workload == "e2e_base32":
+        args.workload, args.e2e = "kfull", "on"
+    if args.overlap != "none":
+        args.pipeline = 1
+    return args
 
-    # stdout carries exactly ONE JSON line: everything libraries print meanwhile (RCCL's init banner ...) goes to stderr
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
 
+def make_emitter(path):
+    """Children publish their (partial) results by atomically rewriting one JSON file: whatever was measured before
+    a GPU fault is still there for the parent."""
+    def emit(obj):
+        if not path:
+            return
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(obj, f)
+        os.replace(tmp, path)
+    return emit
+
+
+def role_kernel(args):
+    """The kernel-level measurement (one process per GPU).  Publishes the single-batch-in-flight line as soon as it
+    exists, then the line with `--pipeline` batches in flight."""
+    emit = make_emitter(args.out)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)                      # rank r of the node drives GPU r
+        dev = torch.device("cuda", local_rank)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     dist = None
     force_dist = os.environ.get("WT_BENCH_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank
+    ranks_seen = 1
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # nccl IS RCCL on ROCm
+        ranks_seen = dist.get_world_size()
+    if args.inject_fault == "kernel":
+        os.abort()
 
-    if args.workload == "e2e_base32":
-        args.workload, args.e2e = "kfull", "on"
     cfg = WORKLOADS[args.workload]
-    w = make_workload(dev, cfg, seed=1234 + rank)
     n = cfg["n_chunks"]
+    if dry:
+        w = dict(cfg=cfg, jumps=torch.zeros(n * (cfg["T"] + 1), dtype=torch.int32), logprob=torch.zeros(n * cfg["T"]))
+    else:
+        w = make_workload(dev, cfg, seed=1234 + rank)
     cfg = w["cfg"]
 
-    if args.overlap != "none":
-        args.pipeline = 1
     gatherers = None
     if world > 1 or force_dist:
         from whisper_timestamped.sharding import ResultGatherer
@@ -630,7 +668,7 @@ def main():
     # --pipeline N: N output-buffer sets over the same inputs, one stream each
     pipe = [w]
     pipe_streams = [None]
-    if args.pipeline > 1:
+    if args.pipeline > 1 and not dry:
         n_cost = w["cost"].numel()
         for _ in range(args.pipeline - 1):
             c = dict(w)
@@ -642,6 +680,11 @@ def main():
         pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
 
     def full_step(ev=None, k=0, pipelined=False):
+        if dry:
+            time.sleep(2e-4)
+            if gatherers is not None:
+                gatherers[k % args.pipeline if pipelined else 0].gather(w["jumps"], w["logprob"])
+            return
         if pipelined:
             j = k % args.pipeline
             with torch.cuda.stream(pipe_streams[j]):
@@ -655,21 +698,21 @@ def main():
 
     for k in range(args.warmup):
         full_step(None, k)
-    torch.cuda.synchronize()
+    sync()
     if args.pipeline > 1:
         for k in range(max(args.warmup, 2 * args.pipeline)):       # every stream's scratch arenas exist before the timing
             full_step(None, k, pipelined=True)
         if gatherers is not None:
             for g_ in gatherers:
                 g_.drain()
-        torch.cuda.synchronize()
+        sync()
 
     graph = None
     if args.graph:
         # ONE captured HIP graph holding `pipeline` steps: batch 0 on the capture stream, every other batch on a branch
         # forked at the head of the graph and joined at its end (independent branches: the runtime may run them side by
         # side, as the eager two-stream pipeline does, without the per-launch host cost)
-        assert args.overlap == "none" and gather_buf is None, "--graph: single rank"
+        assert args.overlap == "none" and gather_buf is None and not dry, "--graph: single rank"
         cap = torch.cuda.Stream(device=dev)
         sides = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline - 1)]
         cap.wait_stream(torch.cuda.current_stream())
@@ -691,6 +734,8 @@ def main():
         torch.cuda.synchronize()
 
     def make_events():
+        if dry:
+            return None
         if args.overlap != "none":
             return {st: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for st in STAGES}
         order = [stage for lane in LANES for stage in lane]
@@ -704,7 +749,7 @@ def main():
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks; seconds."""
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         if graph is not None and (pipelined or args.pipeline == 1):
             reps, rem = divmod(args.steps, args.pipeline)     # one replay = `pipeline` steps
@@ -718,7 +763,7 @@ def main():
         if gatherers is not None:
             for g_ in (gatherers if pipelined else gatherers[:1]):
                 g_.drain()
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -726,7 +771,10 @@ def main():
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        if not pipelined and (graph is None or args.pipeline > 1):
+        if dry:
+            for s in STAGES:
+                stage_samples[s].extend([0.04] * args.steps)
+        elif not pipelined and (graph is None or args.pipeline > 1):
             for s in STAGES:
                 stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
         return el
@@ -737,6 +785,7 @@ def main():
         torch.cuda.synchronize()
         for s in STAGES:
             stage_samples[s].extend(evs[k][s][0].elapsed_time(evs[k][s][1]) for k in range(args.steps))
+
     def measure(pipelined):
         regions = [timed_region(pipelined)]
         n_regions = args.repeats or int(min(2000, max(5, np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
@@ -744,38 +793,25 @@ def main():
             regions.append(timed_region(pipelined))
         return regions
 
-    single_regions = measure(False)                  # one batch in flight: also the per-stage times and the roofline
-    regions = measure(True) if args.pipeline > 1 else single_regions
-    elapsed = float(np.median(regions))
+    def check_results(sets):
+        """sanity inside the bench: the ridge is recovered and log-probs are finite (every buffer set given)"""
+        if dry:
+            return
+        torch.cuda.synchronize()
+        for c in sets[1:]:
+            assert torch.equal(c["host_result"], w["host_result"]), "pipelined steps disagree with the first buffer set"
+        hj = w["host_jumps"].numpy()
+        devs = []
+        for k, d in enumerate(w["descs"]):
+            Tk, Fk, j0 = int(d["T"]), int(d["F"]), int(d["jumps_offset"])
+            j = hj[j0:j0 + Tk + 1]
+            assert j[0] == 0 and j[-1] == Fk - 1 and (np.diff(j) >= 0).all()
+            devs.append(np.abs(j[:-1] - np.asarray(w["stairs"][k])))
+        assert np.median(np.concatenate(devs)) <= 3
+        assert np.isfinite(w["host_logprob"].numpy()).all()
 
-    # sanity inside the bench: the ridge is recovered and log-probs are finite (every buffer set of the pipeline)
-    torch.cuda.synchronize()
-    for c in pipe[1:]:
-        assert torch.equal(c["host_result"], w["host_result"]), "pipelined steps disagree with the first buffer set"
-    hj = w["host_jumps"].numpy()
-    devs = []
-    for k, d in enumerate(w["descs"]):
-        Tk, Fk, j0 = int(d["T"]), int(d["F"]), int(d["jumps_offset"])
-        j = hj[j0:j0 + Tk + 1]
-        assert j[0] == 0 and j[-1] == Fk - 1 and (np.diff(j) >= 0).all()
-        devs.append(np.abs(j[:-1] - np.asarray(w["stairs"][k])))
-    assert np.median(np.concatenate(devs)) <= 3
-    assert np.isfinite(w["host_logprob"].numpy()).all()
-
-    cpu_lines = {}
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and not cfg.get("units"):   # rank 0 at N=1 only (fixed-shape workloads)
-        cpu_lines["cpu_baseline"] = cpu_baseline(cfg, w)
-        cpu_lines["cpu_baseline_1thread"] = cpu_baseline(cfg, w, budget_s=8.0, threads=1)
-
-    e2e = None
-    if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
-        for c in pipe:                                 # the kernel-level inputs are not needed any more
-            for k in ("qk", "logits", "cost", "mel"):
-                c[k] = None
-        torch.cuda.empty_cache()
-        e2e = run_e2e(dev, args, rank, world, dist)
-
-    if rank == 0:
+    def line(regions, single_regions, batches_in_flight):
+        elapsed = float(np.median(regions))
         stage_ms = {s: float(np.median(stage_samples[s])) for s in STAGES}
         ab = algorithmic_bytes(cfg)
         dom = max(stage_ms, key=stage_ms.get)
@@ -783,20 +819,24 @@ def main():
         stages = {s: {"ms": round(stage_ms[s], 4), "alg_MB": round(ab[s] / 1e6, 2),
                       "GBps": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9, 1),
                       "frac_hbm": round(ab[s] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for s in STAGES}
-        ms_per_step = elapsed / args.steps * 1e3
         traffic, traffic_src = committed_traffic(dom, args.workload)
-        out = {
+        return {
             "metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks",
             "value": round(world * n * 30.0 * args.steps / elapsed, 1),
             "unit": "audio-seconds/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "DRY RUN: no kernels ran, the numbers mean nothing",
             "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
+                       "dtw_oracle": "published dtw-python algorithm (symmetric1, strict-< tie order), unpinned against the "
+                                     "package itself: absent from the image (tests/test_oracle.py pins it on exhaustive "
+                                     "path enumeration and on transformers' DTW for tie-free inputs)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
-                       "hip_graph": bool(args.graph), "batches_in_flight": args.pipeline,
-                       "result_gather": f"rccl gather to rank 0, one message per {args.gather_every} steps" if gatherers is not None else "none"},
+                       "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
+                       "rccl_ranks_seen": ranks_seen,
+                       "result_gather": f"{'gloo (dry run)' if dry else 'rccl'} gather to rank 0, one message per {args.gather_every} steps"
+                                        if gatherers is not None else "none"},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region",
                        "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
                        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
@@ -811,16 +851,151 @@ def main():
                          "achievable_copy_GBps_guide": 6290.0, "achievable_read_GBps_probe": 6600.0},
             "stages": stages,
         }
-        if e2e is not None:
-            out["e2e"] = e2e
-        out.update(cpu_lines)
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+
+    single_regions = measure(False)                  # one batch in flight: also the per-stage times and the roofline
+    check_results(pipe[:1])
+    if rank == 0:
+        emit(line(single_regions, single_regions, 1))     # published before the multi-stream pass starts
+    regions = measure(True) if args.pipeline > 1 else single_regions
+    check_results(pipe)
+    if rank == 0:
+        emit(line(regions, single_regions, args.pipeline))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def role_cpu(args):
+    """cpu_baseline: the oracle on the host cores over a bounded sample of the same workload (the sample is drawn on
+    the GPU with the kernel leg's generator, then moved to the host)."""
+    emit = make_emitter(args.out)
+    dev = torch.device("cuda", 0)
+    cfg = WORKLOADS[args.workload]
+    w = make_workload(dev, cfg, seed=1234)
+    out = {"cpu_baseline": cpu_baseline(w["cfg"], w)}
+    emit(out)
+    out["cpu_baseline_1thread"] = cpu_baseline(w["cfg"], w, budget_s=8.0, threads=1)
+    emit(out)
+
+
+def role_e2e(args):
+    emit = make_emitter(args.out)
+    if args.inject_fault == "e2e_" + args.leg:
+        emit({"marker": "about to abort"})
+        os.abort()
+    torch.cuda.set_device(0)
+    run_e2e(torch.device("cuda", 0), args, args.leg, emit)
+
+
+def run_child(role, extra, timeout_s, env=None):
+    """One measuring leg in a child process of this script.  Returns (result dict or None, error string or None):
+    the result is whatever the child published before it ended, however it ended."""
+    import subprocess
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix=f"wt_bench_{role}_", suffix=".json")
+    os.close(fd)
+    os.unlink(path)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--role", role, "--out", path] + list(extra)
+    err = None
+    try:
+        rc = subprocess.run(cmd, stdout=sys.stderr, timeout=timeout_s, env=env).returncode      # children never write to stdout
+        if rc < 0:
+            err = f"signal {-rc}"
+        elif rc != 0:
+            err = f"exit {rc}"
+    except subprocess.TimeoutExpired:
+        err = f"timeout after {timeout_s} s"
+    res = None
+    if os.path.exists(path):
+        try:
+            res = json.load(open(path))
+        except Exception:                       # noqa: BLE001
+            res = None
+        os.unlink(path)
+    return res, err
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU: RCCL "
+                         f"refuses two ranks on one device)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def orchestrate(args):
+    """The process the driver starts (one per rank).  It never touches the GPU itself: the kernel-level measurement,
+    the CPU baselines and each transcribe()-level leg run in child processes that publish their results as they go,
+    so a GPU fault in any leg costs that leg (reported as {"error": ...}), not the line.  stdout carries exactly ONE
+    JSON line (rank 0), printed when every leg has ended; the headline is also logged to stderr as soon as the
+    kernel leg has produced it."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        self_launch(args)                                  # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(world_env or "1")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    inject = ["--inject-fault", ""]                        # a retried leg is not aborted again
+    out, err = run_child("kernel", [], 900)
+    attempts = 1
+    if (out is None or err) and world == 1:
+        # A leg that died is run once more and the line says so: the number is reported, the fault is not hidden.
+        first = {"error": err, "published_before_the_fault": sorted(out) if out else None}
+        out2, err2 = run_child("kernel", inject, 900)
+        attempts = 2
+        if out2 is not None and (out is None or not err2):
+            out, err = out2, err2
+        out = out or {}
+        out["kernel_leg_first_attempt"] = first
+    if rank != 0:
+        sys.exit(1 if err else 0)
+    if out is None:
+        out = {"metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks", "value": None, "unit": "audio-seconds/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
+    if err:
+        out["kernel_leg_error"] = err
+    out["kernel_leg_attempts"] = attempts
+    print("[bench] kernel-level headline: " + json.dumps({k: out.get(k) for k in ("value", "unit", "ms_per_step", "roofline")}),
+          file=sys.stderr, flush=True)
+    if world == 1 and not args.dry_run:
+        fixed_shape = not WORKLOADS[args.workload].get("units_per_chunk")
+        if not args.no_cpu_baseline and fixed_shape:       # rank 0 at N=1 only (fixed-shape workloads)
+            cpu, cerr = run_child("cpu", [], 600)
+            out.update(cpu or {})
+            if cerr:
+                out["cpu_baseline_error"] = cerr
+        if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
+            e2e, e1 = run_child("e2e", ["--leg", "fp32"], 900)
+            e2e = e2e or {}
+            if e1:
+                e2e["error"] = e1
+            half, e2 = run_child("e2e", ["--leg", "fp16"], 900)
+            half = half or {}
+            half.pop("marker", None)
+            e2e.update(half)
+            if e2:
+                e2e["fp16_legs_error"] = e2
+            out["e2e"] = e2e
+    print(json.dumps(out), flush=True)
+    if out.get("value") is None:
+        sys.exit(1)
+
+
+def main():
+    args = parse_args()
+    if args.role == "orchestrate":
+        return orchestrate(args)
+    # children: stdout belongs to the parent's single JSON line -- everything libraries print goes to stderr
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    {"kernel": role_kernel, "cpu": role_cpu, "e2e": role_e2e}[args.role](args)
 
 
 if __name__ == "__main__":
