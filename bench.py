@@ -355,10 +355,17 @@ def cpu_baseline(cfg, w, budget_s=12.0, threads=None, distinct=32):
     from oracle import align_ref as O
     T = cfg["T"]
     nd = min(distinct, cfg["n_chunks"])
-    qk = w["qk"][:nd].float().cpu()
-    logits = w["logits"][: nd * T].cpu()
+    def to_host(t):
+        """device -> page-locked host memory, chunk by chunk (the runtime never has to lock GBs of pageable memory
+        on the fly for one copy)"""
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        for a in range(0, t.shape[0], 4):
+            host[a:a + 4].copy_(t[a:a + 4])
+        return host
+    qk = to_host(w["qk"][:nd].float())
+    logits = to_host(w["logits"][: nd * T].view(nd, T, -1)).view(nd * T, -1)
     tokens = w["tokens"][: nd * T].cpu().numpy()
-    pcm = w["pcm"][:nd].cpu()
+    pcm = to_host(w["pcm"][:nd])
     before = torch.get_num_threads()
     if threads:
         torch.set_num_threads(threads)

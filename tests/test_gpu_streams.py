@@ -1,0 +1,64 @@
+"""Several batches in flight on distinct HIP streams (the configuration bench.py defaults to): every stream owns its
+inputs, outputs and -- inside the library -- its scratch arenas.  Each buffer set is first run alone (its reference;
+set 0's reference is held against the oracle), then 2 and 3 sets run concurrently for >= 200 steps and every set must
+reproduce its own reference bit for bit at every checkpoint: a scratch arena shared between streams, a DTW plane slot
+written by the wrong workgroup or a stale result record shows up as a difference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import align_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(bench, dev, seed, n_chunks):
+    cfg = dict(bench.WORKLOADS["kfull"], n_chunks=n_chunks)
+    return bench.make_workload(dev, cfg, seed=seed)
+
+
+def _snapshot(w):
+    return {k: w[k].clone() for k in ("result", "mel", "pad", "gmax", "cost")}
+
+
+@pytest.mark.parametrize("n_sets,n_chunks,steps", [(2, 32, 200), (3, 32, 210), (3, 5, 300)])
+def test_batches_in_flight_on_distinct_streams(n_sets, n_chunks, steps):
+    import bench
+    dev = torch.device("cuda", 0)
+    sets = [_set(bench, dev, 900 + j, n_chunks) for j in range(n_sets)]
+    refs = []
+    for w in sets:                                   # each set alone, on the default stream
+        bench.run_step(w)
+        torch.cuda.synchronize()
+        refs.append(_snapshot(w))
+    # set 0 against the oracle: DTW jumps bit-exact for the GPU's cost matrix, cost and log-probs within the parity bars
+    w, cfg = sets[0], sets[0]["cfg"]
+    T, F = cfg["T"], cfg["F"]
+    jumps = w["jumps"].cpu().numpy()
+    for b in (0, n_chunks - 1):
+        d = w["descs"][b]
+        c = w["cost"][int(d["cost_offset"]):int(d["cost_offset"]) + T * F].reshape(T, F).cpu().numpy()
+        ref = O.cost_matrix_ref(w["qk"][b].float().cpu(), 9, 1.0, None, 0)
+        assert np.abs(c - ref).max() / np.abs(ref).max() < 2e-6
+        r = O.dtw_ref(c.astype(np.float64))
+        assert np.array_equal(jumps[int(d["jumps_offset"]):int(d["jumps_offset"]) + T + 1], O.jumps_from_path(r.index1s, r.index2s))
+        lp = w["logprob"][b * T:(b + 1) * T].cpu()
+        want = O.token_logprob_gather_ref(w["logits"][b * T:(b + 1) * T].cpu(), w["tokens"][b * T:(b + 1) * T].cpu().numpy())
+        assert (lp - want).abs().max() < 2e-5
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_sets)]
+    for w in sets:
+        for k in ("result", "mel", "cost"):
+            w[k].zero_()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        j = k % n_sets
+        with torch.cuda.stream(streams[j]):
+            bench.run_step(sets[j])
+        if k % 50 == 49 or k == steps - 1:           # checkpoint: every set equals its own single-stream reference
+            torch.cuda.synchronize()
+            for j2, (w, ref) in enumerate(zip(sets, refs)):
+                if k < n_sets and j2 > k:
+                    continue
+                for name, want in ref.items():
+                    assert torch.equal(w[name], want), f"step {k}: buffer set {j2}: {name} differs from its single-stream reference"
+                assert torch.equal(w["host_result"], ref["result"].cpu())

@@ -38,9 +38,8 @@ __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// Asynchronous copy of one head's row (F logits) into dst[4 .. 4+F): fp32 goes
-// HBM -> LDS directly (global_load_lds, no VGPR round trip, completion tracked by
-// vmcnt); fp16 (a build-side storage option) is converted through registers.
+// Asynchronous copy of one head's row (F logits) into dst[4 .. 4+F): HBM -> LDS directly (global_load_lds, no VGPR
+// round trip, completion tracked by vmcnt).
 // 16 bytes per lane and instruction (global_load_lds_dwordx4: lane l of a load lands at base + 16*l): a 1500-frame row
 // is 6 instructions instead of 24.  Groups of four floats that do not lie fully inside the row re-read the last full
 // group (their LDS slots are never used) -- except that the straddling group's slots hold the row's last F % 4
@@ -65,32 +64,28 @@ __device__ __forceinline__ float stage_row(const float *__restrict__ src, float 
     }
     return src[min(4 * nvec + lane, F - 1)];
 }
+// fp16 rows (a build-side storage option, BASELINE config 5) take the same road: the halves travel HBM -> LDS AS THEY
+// ARE (global_load_lds_dwordx4, 8 halves per lane and instruction: a 1500-frame row is 3 instructions) and are
+// converted on the way from LDS to registers.  The DMA wants a 4-byte aligned source: a row that starts on an odd
+// element is fetched from one element earlier (`sh` = 1: the same 4-byte word, i.e. inside the same tensor) and every
+// LDS index below carries that shift.  hs[8 + sh + f] = element f; only full groups of 8 halves inside [0, F + sh) are
+// copied, the last (F + sh) % 8 halves travel in a register (lanes 0..6) and are written once the row has landed,
+// like the fp32 tail.  Returns this lane's tail half (raw bits).
 template <int C>
-__device__ __forceinline__ float stage_row(const __half *__restrict__ src, float *dst, int F, int nch, int lane) {
-    // fp16 storage (build-side option): two halves per lane and load when the row starts on a 4-byte boundary
-    // (half the load instructions, full 4-byte lanes), element-wise otherwise; converted through registers.
-    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0 && F >= 2) {  // wave-uniform
-        constexpr int P = C / 2;                         // dword chunks of 64 lanes
-        const int npair = F >> 1;                        // full pairs only: nothing is read past the row
-        __half2 v[P];
+__device__ __forceinline__ unsigned short stage_row_h(const __half *__restrict__ src, unsigned short *hs, int F, int sh, int lane) {
+    const unsigned short *srcA = reinterpret_cast<const unsigned short *>(src) - sh;   // 4-byte aligned
+    const int Fh = F + sh;
+    const int nvec = Fh >> 3;
 #pragma unroll
-        for (int k = 0; k < P; ++k)
-            v[k] = (k * 64 < npair) ? reinterpret_cast<const __half2 *>(src)[min(k * 64 + lane, npair - 1)] : __half2();
-        const float last = __half2float(src[F - 1]);
-#pragma unroll
-        for (int k = 0; k < P; ++k)
-            if (k * 64 < npair)                          // (clamped lanes write duplicates beyond the pairs: fixed below)
-                *reinterpret_cast<float2 *>(dst + 4 + 2 * (k * 64 + lane)) = __half22float2(v[k]);
-        if (lane == 0) dst[4 + F - 1] = last;            // odd F: the unpaired last element (same-wave LDS order)
-        return last;
+    for (int k = 0; k < (C + 7) / 8 + 1; ++k) {
+        const int g = k * 64 + lane;
+        if (g < nvec) {  // per lane: a lane without a full group neither reads nor writes (CAP is not a multiple of 512 halves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + 8 * g),
+                                             (__attribute__((address_space(3))) void *)(hs + 8 + k * 512), 16, 0,
+                                             2 /* cpol nt: every logit is read exactly once */);
+        }
     }
-    float v[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) v[k] = (k < nch) ? __half2float(src[min(k * 64 + lane, F - 1)]) : 0.f;
-#pragma unroll
-    for (int k = 0; k < C; ++k)
-        if (k < nch) dst[4 + k * 64 + lane] = v[k];
-    return v[0];
+    return srcA[min(8 * nvec + lane, Fh - 1)];
 }
 
 // C = elements per lane; an instantiation can serve any F <= C*64 (the launch passes the F range it is used for).
@@ -102,8 +97,11 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
                                                       float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
                                                       int f_lo, int f_hi) {
     constexpr int CAP = C * 64;
-    constexpr int BUF = CAP + 8;
-    __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];  // per wave: double-buffered row
+    constexpr bool HALF = sizeof(QT) == 2;
+    // per wave: double-buffered row.  fp32: xs[4 + f] = element f (+ 4 halo slots each side).  fp16: raw halves,
+    // hs[8 + sh + f] = element f (sh = 0/1, see stage_row_h), + halo, + the qword the shifted register load over-reads.
+    constexpr int BUF = HALF ? (CAP + 32) / 2 : CAP + 8;           // in floats (fp16: CAP + 32 halves)
+    __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -132,33 +130,75 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     // product this kernel used before: same worst error against the oracle, 2.9e-7 of the matrix maximum; -7 % time)
     const f2 cexp = (f2){qk_scale * 1.44269502162933349609375f, qk_scale * 1.44269502162933349609375f};
 
-    constexpr bool DMA16 = sizeof(QT) == 4;   // fp32 rows: 16-byte LDS-DMA + a register for the last F % 4 elements
-    const int tail0 = F & ~3, ntail = (DMA16 && F >= 4) ? (F & 3) : 0;
-    float tail = stage_row<C>(row0 + (int64_t)head_idx[0] * d.head_stride, lds[wave][0], F, nch, lane);
+    // fp32 rows: 16-byte LDS-DMA + a register for the last F % 4 elements; fp16 rows: the same with 8 halves per lane
+    const int tail0 = F & ~3, ntail = (!HALF && F >= 4) ? (F & 3) : 0;
+    // fp16: every head's row of this token starts at the same parity (head_stride elements apart: the shift is
+    // recomputed per head, it is one AND)
+    float tail = 0.f;
+    unsigned short tailh = 0;
+    int sh = 0;
+    auto stage = [&](int a) __attribute__((always_inline)) {
+        const QT *src = row0 + (int64_t)head_idx[a] * d.head_stride;
+        if constexpr (HALF) {
+            sh = (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 1);
+            tailh = stage_row_h<C>(src, reinterpret_cast<unsigned short *>(lds[wave][a & 1]), F, sh, lane);
+        } else {
+            tail = stage_row<C>(src, lds[wave][a & 1], F, nch, lane);
+        }
+    };
+    stage(0);
     for (int a = 0; a < n_heads; ++a) {
-        float *xs = lds[wave][a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+        float x[C + 8];
         wait_vmcnt0();                 // head a's row has landed in LDS
         wave_lds_fence();
-        if (lane < ntail) xs[4 + tail0 + lane] = tail;   // (the group that straddles the end of the row)
-        wave_lds_fence();
-        if (lane < 8) {
-            const float hv = xs[4 + hsrc];
-            xs[4 + hpos] = hv;
-        }
-        wave_lds_fence();
-
-        float x[C + 8];
-        const float4 *xp = reinterpret_cast<const float4 *>(xs + lane * C);
+        if constexpr (HALF) {
+            unsigned short *hs = reinterpret_cast<unsigned short *>(lds[wave][a & 1]);
+            const int Fh = F + sh;
+            if (lane < (Fh & 7)) hs[8 + (Fh & ~7) + lane] = tailh;   // (the group that straddles the end of the row)
+            wave_lds_fence();
+            if (lane < 8) {
+                const unsigned short hv = hs[8 + sh + hsrc];
+                hs[8 + sh + hpos] = hv;
+            }
+            wave_lds_fence();
+            // this lane's C + 8 elements start at half 4 + sh + lane * C: read the dwords from half 4 + lane * C (8-byte
+            // aligned) and, for odd starts, funnel-shift neighbouring dwords by one half
+            constexpr int NQ = (C + 8) / 4 + 1;
+            const uint2 *qp = reinterpret_cast<const uint2 *>(hs + 4 + lane * C);
+            unsigned w[2 * NQ];
 #pragma unroll
-        for (int k = 0; k < (C + 8) / 4; ++k) {
-            const float4 r = xp[k];
-            x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
+            for (int k = 0; k < NQ; ++k) {
+                const uint2 r = qp[k];
+                w[2 * k] = r.x; w[2 * k + 1] = r.y;
+            }
+            const bool odd = sh != 0;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < (C + 8) / 2; ++k) {
+                const unsigned v = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 16) : w[k];
+                const __half2 h2 = *reinterpret_cast<const __half2 *>(&v);
+                const float2 f2v = __half22float2(h2);
+                x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
+            }
+        } else {
+            float *xs = lds[wave][a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+            if (lane < ntail) xs[4 + tail0 + lane] = tail;   // (the group that straddles the end of the row)
+            wave_lds_fence();
+            if (lane < 8) {
+                const float hv = xs[4 + hsrc];
+                xs[4 + hpos] = hv;
+            }
+            wave_lds_fence();
+            const float4 *xp = reinterpret_cast<const float4 *>(xs + lane * C);
+#pragma unroll
+            for (int k = 0; k < (C + 8) / 4; ++k) {
+                const float4 r = xp[k];
+                x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
+            }
         }
         // Row a now lives in registers: start streaming head a+1 into the other buffer; it lands while
         // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
         // that follows an LDS-DMA, which would serialise the copy with the reads.)
-        if (a + 1 < n_heads)
-            tail = stage_row<C>(row0 + (int64_t)head_idx[a + 1] * d.head_stride, lds[wave][(a + 1) & 1], F, nch, lane);
+        if (a + 1 < n_heads) stage(a + 1);
         // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
         float lo[C + 6], mi[C + 6], hi[C + 6];
 #pragma unroll
@@ -196,7 +236,8 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
     const float nh = (float)n_heads;
-    float *xs = lds[wave][0];
+    float *xs = &lds[wave][0][0];   // (fp16: the transposition spans both row buffers -- 2 * BUF >= CAP floats; all copies have landed)
+    static_assert(2 * BUF >= CAP, "the output transposition fits the wave's two row buffers");
     wave_lds_fence();
     float4 *op = reinterpret_cast<float4 *>(xs + lane * C);
     if ((n_heads & (n_heads - 1)) == 0) {  // power of two: x * (1/n) == x / n exactly

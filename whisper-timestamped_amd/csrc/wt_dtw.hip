@@ -102,19 +102,19 @@ __device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1
                  "v_cmp_lt_f64 vcc, %4, %5\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
                  : "+v"(wa), "+v"(wb) : "v"(a1), "v"(a2), "v"(b1), "v"(b2) : "vcc");
 }
-// The two plane words of a finished block -> the unit's scratch slot.  Issued as inline assembly on purpose: a store
-// the compiler knows about would share the vmcnt counter with the cost prefetch, and with loads AND stores pending
-// hipcc waits with vmcnt(0) at the next use of prefetched data -- the memory latency the prefetch exists to hide,
-// once per block.  Unknown to the compiler, the store only makes its counted waits conservative by one (loads return
-// in order among themselves; the store was issued a whole block earlier).  gfx9 reads store data at issue: the
-// registers may be reused at once.  The kernel waits for these stores itself before the backtrack (wait_vmcnt0).
-// The address is a per-lane 64-bit VGPR pair, not SGPR base + offset: the hazard recogniser does not look inside an
-// asm statement, and in the register-starved instantiations hipcc reloads a spilled base with v_readlane (a VALU write
-// of an SGPR) right in front of it -- a VMEM instruction that reads that SGPR within 5 wait states sees the old value
-// (measured: memory faults in dtw_kernel<true, true> only).  VGPR operands are interlocked by the hardware.
-__device__ __forceinline__ void store_plane_words(const uint2 *addr, uint32_t wa, uint32_t wb) {
-    const uint64_t data = (uint64_t)wa | ((uint64_t)wb << 32);
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(addr), "v"(data) : "memory");
+// The two plane words of a finished block -> the unit's scratch slot: ONE 8-byte buffer store per lane on a descriptor
+// of the slot (base = the unit's first plane word, range = its slot): the compiler sees the store (it keeps its own
+// vmcnt / hazard bookkeeping -- round 2 issued it as inline assembly behind the compiler's back) and the hardware
+// range-checks it: a plane word can only land inside the unit's own slot, whatever the offset.  The backtrack reads
+// the words back through the same descriptor (out-of-range reads return 0).
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_plane_words(__amdgpu_buffer_rsrc_t slot, int boff, uint32_t wa, uint32_t wb) {
+    const uint2v data = {wa, wb};
+    __builtin_amdgcn_raw_buffer_store_b64(data, slot, boff, 0, 0);
+}
+__device__ __forceinline__ uint2 load_plane_words(__amdgpu_buffer_rsrc_t slot, int boff) {
+    const uint2v v = __builtin_amdgcn_raw_buffer_load_b64(slot, boff, 0, 0);
+    return make_uint2(v.x, v.y);
 }
 
 // One 32-step block of the anti-diagonal sweep.
@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
 
     // [block][row] (.x = plane A word, .y = plane B word) in this unit's slot of the scratch arena
     uint2 *plane = planes + (size_t)blockIdx.x * plane_stride;
+    const __amdgpu_buffer_rsrc_t pbuf = __builtin_amdgcn_make_buffer_rsrc(plane, 0, (int)plane_stride * 8, 0x00020000);
     double *bnd = reinterpret_cast<double *>(smem);          // [nw-1][bpitch], bnd[w][64 + j]
     double *park = bnd + (size_t)(nw - 1) * bpitch;          // [nw-1][DUMP]
     int *prog = reinterpret_cast<int *>(park + (size_t)(nw - 1) * DUMP);  // [nw-1]
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     double *pub = (lane == 63) ? bnd + (size_t)pw * bpitch + 1 : park + (size_t)pw * DUMP + lane;
     const int pubinc = (lane == 63) ? BLK : 0;
     const double *erow = bnd + (size_t)(wave > 0 ? wave - 1 : 0) * bpitch;
-    const uint2 *pword = plane + i;                          // this lane's word pair of the current block
+    int pword = 8 * i;                                       // byte offset of this lane's word pair of the current block
 
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
@@ -244,8 +245,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
                 }
             }
             sweep_block<EDGE, PUBLISH, DIST, FIRST, NOUP>(cur, g, u0, u1, edge, wa, wb, pub, s0, sfinal, gfinal);
-            store_plane_words(pword, wa, wb);
-            pword += rowsP;
+            store_plane_words(pbuf, pword, wa, wb);
+            pword += 8 * rowsP;
             if (PUBLISH) {
                 pub += pubinc;
                 if (lane == 0) {
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     }
     if (DIST && i == T - 1) dist[blockIdx.x] = gfinal;
     WT_STAMP(4 + wave);
-    wait_vmcnt0();          // this wave's plane words have left for the L2 (the compiler does not know about them)
-    __syncthreads();
+    wait_vmcnt0();          // this wave's plane words have reached the L2 ...
+    __syncthreads();        // ... before any wave of the workgroup reads them back
     if (wave != 0) return;
     WT_STAMP(8);
 
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
         const int win = max((s >> 5) - 1, 0);
         const int base = 32 * win;
         const int top = bi;
-        const uint2 *rowp = plane + (size_t)win * rowsP + max(bi - lane, 0);   // lanes read consecutive rows: coalesced
-        const uint2 w0 = rowp[0], w1 = rowp[rowsP];
+        const int rowp = 8 * (win * rowsP + max(bi - lane, 0));                // lanes read consecutive rows: coalesced
+        const uint2 w0 = load_plane_words(pbuf, rowp), w1 = load_plane_words(pbuf, rowp + 8 * rowsP);
         const int a0 = (int)w0.x, b0 = (int)w0.y, a1 = (int)w1.x, b1 = (int)w1.y;
         bool more;
         do {   // one row per iteration, no memory access, one taken branch
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
             const int s = bj + (bi & 63);
             const int key = (s >> 5) * rowsP + bi;
             if (key != have) {
-                const uint2 AB = plane[key];
+                const uint2 AB = load_plane_words(pbuf, 8 * key);
                 ca = __builtin_amdgcn_readfirstlane(AB.x);
                 cb = __builtin_amdgcn_readfirstlane(AB.y);
                 have = key;
@@ -370,13 +371,23 @@ int scratch_dtw(hipStream_t st, size_t bytes, void **out);   // the direction pl
 template <bool DIST, bool TINY, bool NOUP>
 static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes, hipStream_t st) {
-    static std::once_flag once;  // per instantiation; function attributes are per process on one device
-    hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [&] {
-        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY, NOUP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    WT_HIP(attr_rc);
+    // function attributes are per (instantiation, device): set the first time each device launches this one
+    static std::mutex mu;
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    WT_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        set_error("wt_dtw_batch: device ordinal %d out of range", dev);
+        return WT_E_UNSUPPORTED;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!attr_set[dev]) {
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dtw_kernel<DIST, TINY, NOUP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set[dev] = true;
+        }
+    }
     for (int nw = 1; nw <= 4; ++nw) {
         if (maxF[nw] == 0) continue;
         const size_t lds = dtw_lds_bytes(nw, maxF[nw]);

@@ -512,12 +512,19 @@ static int device_cu_count() {
     }
     return cached[dev];
 }
+// __constant__ symbols exist once PER DEVICE: the tables are uploaded the first time each device runs the front end.
 static int upload_tables(hipStream_t st) {
-    static bool done = false;
+    static bool done[64] = {false};
+    int dev = 0;
+    WT_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) {
+        set_error("wt_logmel_batch: device ordinal %d out of range", dev);
+        return WT_E_UNSUPPORTED;
+    }
     std::lock_guard<std::mutex> lk(g_tables_mu);
     static float hann[400];
     static float2 w400[400];
-    if (done) return WT_OK;
+    if (done[dev]) return WT_OK;
     const double PI = 3.14159265358979323846;
     for (int n = 0; n < 400; ++n) {
         hann[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / 400.0));
@@ -527,8 +534,8 @@ static int upload_tables(hipStream_t st) {
     }
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_hann), hann, sizeof(hann), 0, hipMemcpyHostToDevice, st));
     WT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(k_w400), w400, sizeof(w400), 0, hipMemcpyHostToDevice, st));
-    WT_HIP(hipStreamSynchronize(st));  // once per process
-    done = true;
+    WT_HIP(hipStreamSynchronize(st));  // once per device
+    done[dev] = true;
     return WT_OK;
 }
 

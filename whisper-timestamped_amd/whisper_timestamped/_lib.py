@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -118,16 +119,21 @@ def device_ctx(device):
 # Page-locked staging buffers are expensive to create (hipHostMalloc: milliseconds) and tiny here (token matrices,
 # padding indices, gather lists): they are pooled per byte-size bucket and handed back after use.
 _PINNED_FREE = {}
+_PINNED_LOCK = threading.Lock()
 
 
 def _pinned_take(nbytes: int) -> torch.Tensor:
     bucket = max(256, 1 << (max(int(nbytes), 1) - 1).bit_length())
-    free = _PINNED_FREE.setdefault(bucket, [])
-    return free.pop() if free else torch.empty(bucket, dtype=torch.uint8).pin_memory()
+    with _PINNED_LOCK:
+        free = _PINNED_FREE.setdefault(bucket, [])
+        if free:
+            return free.pop()
+    return torch.empty(bucket, dtype=torch.uint8).pin_memory()
 
 
 def _pinned_give(buf: torch.Tensor):
-    _PINNED_FREE.setdefault(buf.numel(), []).append(buf)
+    with _PINNED_LOCK:
+        _PINNED_FREE.setdefault(buf.numel(), []).append(buf)
 
 
 class PinnedUpload:

@@ -19,6 +19,8 @@ from __future__ import annotations
 import logging
 from dataclasses import dataclass
 
+import threading
+
 import numpy as np
 import torch
 
@@ -207,24 +209,31 @@ class Workspace:
     def __init__(self, device):
         self.device = torch.device(device)
         self._free = []
+        self._lock = threading.Lock()
 
     def acquire(self):
-        return self._free.pop() if self._free else _Slot(self.device)
+        with self._lock:
+            if self._free:
+                return self._free.pop()
+        return _Slot(self.device)
 
     def release(self, slot):
-        self._free.append(slot)
+        with self._lock:
+            self._free.append(slot)
 
 
 _WORKSPACES = {}
+_WORKSPACES_LOCK = threading.Lock()
 
 
 def default_workspace(device):
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if device not in _WORKSPACES:
-        _WORKSPACES[device] = Workspace(device)
-    return _WORKSPACES[device]
+    with _WORKSPACES_LOCK:
+        if device not in _WORKSPACES:
+            _WORKSPACES[device] = Workspace(device)
+        return _WORKSPACES[device]
 
 
 class AlignmentBatch:
@@ -271,6 +280,14 @@ class AlignmentBatch:
         ws = self.workspace or default_workspace(dev)
         assert ws.device == dev, f"workspace of {ws.device} used for units on {dev}"
         slot = ws.acquire()
+        try:
+            self._launch_on(slot, ws, units, order, dev, dt, esz, base)
+        except BaseException:
+            ws.release(slot)          # (a refused batch -- WT_E_UNSUPPORTED ... -- must not cost the pool a slot)
+            raise
+        return self
+
+    def _launch_on(self, slot, ws, units, order, dev, dt, esz, base):
         n_units = len(units)
         n_sel = units[0].qk.shape[0]
         desc_bytes = n_units * _lib.SEG_DTYPE.itemsize
@@ -326,7 +343,21 @@ class AlignmentBatch:
         self._n_jumps, self._disfl, self._n_result = n_jumps, disfl, n_result
         self.descs, self.cost, self.jumps = descs.copy(), cost, jumps
         self.extra = slot.result[n_result - self.extra_words:n_result] if self.extra_words else None
+
+    def release(self):
+        """Hand the batch's buffers back to the workspace (keep_cost=True batches hold them until told: the cost
+        matrices live there).  Also the exit of ``with AlignmentBatch(keep_cost=True) as batch:``."""
+        if self._slot is not None:
+            (self.workspace or default_workspace(self._slot.device)).release(self._slot)
+            self._slot = None
+            self.cost = self.jumps = self.extra = None
+
+    def __enter__(self):
         return self
+
+    def __exit__(self, *exc):
+        self.release()
+        return False
 
     def fetch(self):
         """Queue the ONE device->host copy of the result record (KBs) behind whatever has been launched so far."""
@@ -362,9 +393,7 @@ class AlignmentBatch:
             out[order[k]] = finish_unit(u, jm, js)
             self._slot_of[order[k]] = k
         if not self.keep_cost:                       # the cost matrices live in the slot: hand it back unless asked to keep
-            (self.workspace or default_workspace(slot.device)).release(slot)
-            self._slot = None
-            self.cost = self.jumps = self.extra = None
+            self.release()
         return out
 
     def run(self):

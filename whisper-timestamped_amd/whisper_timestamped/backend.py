@@ -88,8 +88,9 @@ def _front_end_matches(original, wt_audio, device, n_mels=80):
     """Once per process and backend function: the HIP front end must reproduce THIS backend's log_mel_spectrogram on a
     probe signal (2 s of noise + a tone; bar 1e-3, observed 3e-5).  A backend with another window / hop / filterbank
     than the one wt_logmel_batch restates is detected here instead of silently shifting every log-mel."""
-    key = id(original)
-    if key not in _FRONT_END_OK:
+    key = (getattr(original, "__module__", None), getattr(original, "__qualname__", None), n_mels) \
+        if callable(original) and getattr(original, "__qualname__", None) else None    # a stable identity, never id()
+    if key is None or key not in _FRONT_END_OK:
         import logging
         import torch
         try:
@@ -106,6 +107,8 @@ def _front_end_matches(original, wt_audio, device, n_mels=80):
             logging.getLogger("whisper_timestamped").warning(
                 "whisper_timestamped: this backend's log_mel_spectrogram differs from the HIP front end; "
                 "using the backend's own (efficient.GPU_FRONT_END is ignored)")
+        if key is None:
+            return ok
         _FRONT_END_OK[key] = ok
     return _FRONT_END_OK[key]
 

@@ -11,6 +11,7 @@ Reference: /root/reference/whisper_timestamped/transcribe.py
 from __future__ import annotations
 
 import string
+import weakref
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -73,16 +74,24 @@ class WordGroups:
         return self.words, self.pieces, self.ids
 
 
-_SINGLE_TOKEN_TEXTS = {}
+_SINGLE_TOKEN_TEXTS = weakref.WeakKeyDictionary()
 
 
 def _single_token_texts(tokenizer):
-    """Per tokenizer object: token id -> its decoded text (a tokenizer's vocabulary does not change)."""
+    """Per tokenizer OBJECT: token id -> its decoded text (a tokenizer's vocabulary does not change).  The cache lives
+    on the object, or in a weak dictionary keyed by it; a tokenizer that allows neither (no __dict__, no weak
+    references) gets no cache -- never one keyed on id(), which a later tokenizer with another vocabulary can inherit."""
     try:
-        cache = tokenizer.__dict__.setdefault("_wt_single_token_texts", {})
+        return tokenizer.__dict__.setdefault("_wt_single_token_texts", {})
     except (AttributeError, TypeError):          # frozen / slotted tokenizer objects
-        cache = _SINGLE_TOKEN_TEXTS.setdefault(id(tokenizer), {})
-    return cache
+        pass
+    try:
+        cache = _SINGLE_TOKEN_TEXTS.get(tokenizer)
+        if cache is None:
+            cache = _SINGLE_TOKEN_TEXTS[tokenizer] = {}
+        return cache
+    except TypeError:                            # not weak-referenceable / unhashable
+        return {}
 
 
 def split_tokens_on_unicode(tokens, tokenizer, remove_punctuation_from_words=False, isolate_punctuations=False):
