@@ -224,6 +224,18 @@ def _stage_calls(w):
         _lib._check(L.wt_dtw_batch(w["cost"].data_ptr(), w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n_units,
                                    w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
 
+    if w.get("align") == "fused":
+        # ONE entry point for cost + DTW (wt_align_batch_v3): units of the per-segment shape take the fused small-unit
+        # kernel (cost, DTW, backtrack in one workgroup, the matrix stays in LDS), the others the batched kernels.  The
+        # whole of it is timed as the "cost" stage; the "dtw" stage is empty.
+        def cost(st):   # noqa: F811
+            _lib._check(L.wt_align_batch_v3(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data,
+                                            w["descs_dev"].data_ptr(), n_units, w["head_idx"].data_ptr(), cfg["A"], 9, 1.0,
+                                            w["cost"].data_ptr(), w["jumps"].data_ptr(), 0, 0, 0, 0, 0, st), "wt_align_batch_v3")
+
+        def dtw(st):    # noqa: F811
+            pass
+
     def logprob(st):
         _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n_rows, V, w["tokens"].data_ptr(), 0, 0,
                                               w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
@@ -332,13 +344,18 @@ def run_step(w, ev=None, streams=None):
     w["host_result"].copy_(w["result"], non_blocking=True)
 
 
-def algorithmic_bytes(cfg):
-    """Per launch (= per step on one rank), SURVEY.md 8(d)."""
+def algorithmic_bytes(cfg, fused=False):
+    """Per launch (= per step on one rank), SURVEY.md 8(d).  fused: the small units' matrices never reach HBM (the units
+    that do not qualify still write and re-read theirs: counted)."""
     n, A, V, M = cfg["n_chunks"], cfg["A"], cfg["V"], cfg["n_mels"]
     units = cfg.get("units") or [(cfg["T"], cfg["F"])] * n
     s_in = 2 if cfg.get("qk_dtype") == "f16" else 4
     tf = sum(t * f for t, f in units)
     rows = sum(t for t, _ in units)
+    if fused:
+        big = sum(t * f for t, f in units if t > 64)          # (T <= 64 is the dominant condition of wt_small_unit)
+        return {"logmel": n * (480000 * 4 + M * 3000 * 4), "padding": n * M * 4,
+                "cost": A * tf * s_in + 2 * big * 4 + 4 * (rows + len(units)), "dtw": 0, "logprob": rows * (V * 4 + 8)}
     return {
         "logmel": n * (480000 * 4 + M * 3000 * 4),
         "padding": n * M * 4,                               # an unpadded window is decided by its last column
@@ -586,6 +603,10 @@ def parse_args(argv=None):
                          "inputs are shared), so the 32-CU, latency-bound DTW of one step overlaps the other steps' kernels "
                          "with no cross-stream dependency at all.  The line also carries the single-batch-in-flight time; "
                          "per-stage times and the roofline always come from the single-stream pass")
+    ap.add_argument("--align", default="auto", choices=["auto", "split", "fused"],
+                    help="split: wt_cost_batch then wt_dtw_batch (two timed stages, batched kernels only); fused: ONE "
+                         "wt_align_batch_v3 (small units through the fused kernel; timed as the cost stage); auto = fused for "
+                         "the workloads that have small units (kreal)")
     ap.add_argument("--dtw-cus", type=int, default=32, help="--overlap cumask: CUs reserved for the DTW stream")
     ap.add_argument("--overlap", default="none", choices=["none", "lanes", "dtw", "dtw_logmel", "cumask"],
                     help="none: one stream; lanes: log-mel | cost+DTW | log-prob on three HIP streams; "
@@ -655,6 +676,7 @@ def role_kernel(args):
         w = dict(cfg=cfg, jumps=torch.zeros(n * (cfg["T"] + 1), dtype=torch.int32), logprob=torch.zeros(n * cfg["T"]))
     else:
         w = make_workload(dev, cfg, seed=1234 + rank)
+        w["align"] = args.align if args.align != "auto" else ("fused" if cfg.get("units_per_chunk") else "split")
     cfg = w["cfg"]
 
     gatherers = None
@@ -820,7 +842,7 @@ def role_kernel(args):
     def line(regions, single_regions, batches_in_flight):
         elapsed = float(np.median(regions))
         stage_ms = {s: float(np.median(stage_samples[s])) for s in STAGES}
-        ab = algorithmic_bytes(cfg)
+        ab = algorithmic_bytes(cfg, w.get("align") == "fused")
         dom = max(stage_ms, key=stage_ms.get)
         achieved = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
         stages = {s: {"ms": round(stage_ms[s], 4), "alg_MB": round(ab[s] / 1e6, 2),
@@ -841,6 +863,8 @@ def role_kernel(args):
                                      "path enumeration and on transformers' DTW for tie-free inputs)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
+                       "alignment_entry": "wt_align_batch_v3 (fused small-unit kernel + batched kernels; timed as the cost stage)"
+                                          if w.get("align") == "fused" else "wt_cost_batch + wt_dtw_batch",
                        "rccl_ranks_seen": ranks_seen,
                        "result_gather": f"{'gloo (dry run)' if dry else 'rccl'} gather to rank 0, one message per {args.gather_every} steps"
                                         if gatherers is not None else "none"},

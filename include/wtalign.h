@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 2 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern */
+#define WT_ABI_VERSION 3 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3 */
 
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
@@ -154,7 +154,20 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
                          int step_pattern, int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist,
                          void *stream);
 
-/* wt_cost_batch followed by wt_dtw_batch on the same stream. */
+/* wt_cost_batch followed by wt_dtw_batch on the same stream = perform_word_alignment's numerics (T.py:1540-1581,
+ * 1648-1652) for a batch of units.  Units with T <= 64 whose (T, F) matrix fits a workgroup's LDS -- the reference's
+ * default per-segment call shape (T.py:544-557: T p50 11, F p50 144) -- are aligned by ONE fused kernel (cost, DTW and
+ * backtrack in one workgroup, the matrix never leaves LDS); which path a unit takes depends on its own shape only, and
+ * cost / jumps are bit-identical on both.
+ *   flags : WT_ALIGN_KEEP_COST             cost[] is written for every unit (without it only the units of the
+ *                                          batched kernels leave their matrix there); wt_disfluency_batch needs it
+ *           WT_ALIGN_NO_FUSED_SMALL_UNITS  every unit through the batched kernels (A/B measurements, tests)
+ * wt_align_batch(...) = wt_align_batch_v3(..., WT_ALIGN_KEEP_COST, stream). */
+#define WT_ALIGN_KEEP_COST 1
+#define WT_ALIGN_NO_FUSED_SMALL_UNITS 2
+int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                      const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
+                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, int flags, void *stream);
 int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                    const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);

@@ -105,13 +105,15 @@ def case_step(workload, mode, n_chunks=None):
         assert torch.equal(g["cost"][c0:c0 + n], w["cost"][c0:c0 + n])
 
 
-def case_odd_units(mode, dtype):
-    """Cost + DTW (+ path, distance, disfluency) on units of awkward shapes: F not a multiple of 4, tiny, maximal."""
+def case_odd_units(mode, dtype, flags=1):
+    """Cost + DTW (+ path, distance, disfluency) on units of awkward shapes: F not a multiple of 4, tiny, maximal.
+    flags = WT_ALIGN_KEEP_COST (small units through the fused kernel) or | WT_ALIGN_NO_FUSED_SMALL_UNITS (all batched)."""
     from whisper_timestamped import _lib as L
     import synth
     dev = "cuda:0"
     shapes = [(1, 0, 1), (2, 0, 3), (3, 10, 14), (5, 1, 8), (9, 100, 245), (17, 275, 523), (11, 3, 258), (64, 0, 1500),
-              (65, 219, 1500), (31, 1, 770), (130, 0, 1281), (224, 0, 1500), (255, 7, 1499)]
+              (65, 219, 1500), (31, 1, 770), (130, 0, 1281), (224, 0, 1500), (255, 7, 1499), (64, 3, 258), (16, 0, 1500),
+              (30, 100, 1125), (7, 1, 513)]
     heads = list(range(6))
     qk_list = [synth.synth_qk(300 + k, 6, T, lo=s, hi=e) for k, (T, s, e) in enumerate(shapes)]
     order = L.launch_order([(T, e - s) for T, s, e in shapes])
@@ -137,7 +139,7 @@ def case_odd_units(mode, dtype):
                  pi=f(torch.zeros(n_path, dtype=torch.int32, device=dev)), pj=f(torch.zeros(n_path, dtype=torch.int32, device=dev)),
                  pl=f(torch.zeros(len(shapes), dtype=torch.int32, device=dev)),
                  dist=f(torch.zeros(len(shapes), dtype=torch.float64, device=dev)))
-        L.align_batch(b["qk"], descs, b["dd"], b["hi"], b["cost"], b["jumps"], b["pi"], b["pj"], b["pl"], b["dist"])
+        L.align_batch(b["qk"], descs, b["dd"], b["hi"], b["cost"], b["jumps"], b["pi"], b["pj"], b["pl"], b["dist"], flags=flags)
         st = torch.cuda.current_stream().cuda_stream
         L._check(L.load().wt_disfluency_batch(b["cost"].data_ptr(), b["dd"].data_ptr(), len(shapes), b["jumps"].data_ptr(),
                                               b["starts"].data_ptr(), 0.02, 3.0, st), "wt_disfluency_batch")
@@ -270,6 +272,8 @@ CASES = {
     "step_largev3_fp16": lambda m: case_step("largev3_fp16", m, n_chunks=8),
     "odd_units_f32": lambda m: case_odd_units(m, torch.float32),
     "odd_units_f16": lambda m: case_odd_units(m, torch.float16),
+    "odd_units_f32_batched_only": lambda m: case_odd_units(m, torch.float32, flags=3),
+    "odd_units_f16_batched_only": lambda m: case_odd_units(m, torch.float16, flags=3),
     "logprob": case_logprob,
     "logmel": case_logmel,
     "capture": case_capture,

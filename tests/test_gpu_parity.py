@@ -334,6 +334,78 @@ def test_batch_of_real_shapes_vs_oracle():
     assert worst <= 1
 
 
+def _align_units(shapes, dtype, flags, seed=0, n_heads=8, want_path=True):
+    """cost, jumps, path, distance of a batch of (T, start, end) units through wt_align_batch_v3 with `flags`."""
+    L = _lib()
+    qk_list = [synth.synth_qk(seed + k, n_heads, T, lo=s, hi=e) for k, (T, s, e) in enumerate(shapes)]
+    order = L.launch_order([(T, e - s) for T, s, e in shapes])
+    descs = L.make_descs(len(shapes))
+    offs, off = [], 0
+    for q in qk_list:
+        offs.append(off)
+        off += q.size
+    for d, i in zip(descs, order):
+        T, s, e = shapes[i]
+        q = qk_list[i]
+        d["qk_offset"], d["head_stride"], d["row_stride"] = offs[i], q.shape[1] * q.shape[2], q.shape[2]
+        d["T"], d["F"], d["start_token"], d["pad_from"] = T, e - s, s, (-1 if i % 3 else max((e - s) // 2, 1))
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    qk = torch.from_numpy(np.concatenate([q.ravel() for q in qk_list])).to(DEV).to(dtype)
+    out = dict(descs=descs, order=order, qk_list=qk_list,
+               cost=torch.full((n_cost,), float("nan"), dtype=torch.float32, device=DEV),
+               jumps=torch.full((n_jumps,), -7, dtype=torch.int32, device=DEV),
+               pi=torch.full((n_path,), -7, dtype=torch.int32, device=DEV), pj=torch.full((n_path,), -7, dtype=torch.int32, device=DEV),
+               pl=torch.zeros(len(shapes), dtype=torch.int32, device=DEV), dist=torch.zeros(len(shapes), dtype=torch.float64, device=DEV))
+    L.align_batch(qk, descs, L.descs_to_device(descs, DEV), torch.arange(n_heads, dtype=torch.int32, device=DEV), out["cost"],
+                  out["jumps"], *( (out["pi"], out["pj"], out["pl"], out["dist"]) if want_path else (None, None, None, None)),
+                  flags=flags)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fused_small_units_equal_the_batched_kernels(dtype):
+    """wt_align_batch_v3: units of the reference's per-segment shape (T <= 64, matrix in LDS) take ONE fused kernel
+    (wt_small.hip); cost, jumps, path and distance must be BIT-identical to the batched kernels' (rowmean / colnorm /
+    fix00 / dtw) on the same units -- every F class, tiny units, odd F, pad masks, the largest qualifying shapes -- and
+    the jumps bit-exact against the oracle DTW fed with that cost."""
+    L = _lib()
+    rng = np.random.RandomState(31)
+    shapes = [(1, 0, 1), (1, 5, 9), (2, 0, 3), (3, 10, 14), (5, 1, 8), (9, 100, 245), (11, 3, 147), (17, 275, 523), (11, 3, 258),
+              (64, 0, 256), (64, 1000, 1447), (63, 7, 300), (31, 1, 770), (30, 0, 1025), (16, 0, 1500), (4, 200, 1197), (8, 0, 1792 - 300),
+              (33, 2, 900), (65, 0, 200), (224, 0, 1500), (12, 0, 64), (2, 1400, 1500)]
+    Ts, Fs = synth.draw_real_shapes(77, 60)
+    for T, F in zip(Ts, Fs):
+        s = int(rng.randint(0, 1500 - int(F) + 1))
+        shapes.append((int(T), s, s + int(F)))
+    fused = _align_units(shapes, dtype, L.WT_ALIGN_KEEP_COST)
+    plain = _align_units(shapes, dtype, L.WT_ALIGN_KEEP_COST | L.WT_ALIGN_NO_FUSED_SMALL_UNITS)
+    n_small = 0
+    for k, d in enumerate(fused["descs"]):
+        T, F = int(d["T"]), int(d["F"])
+        c0, j0, p0 = int(d["cost_offset"]), int(d["jumps_offset"]), int(d["path_offset"])
+        a, b = fused["cost"][c0:c0 + T * F], plain["cost"][c0:c0 + T * F]
+        assert torch.equal(a, b), f"cost of unit (T={T}, F={F}) differs between the fused and the batched kernels"
+        assert torch.equal(fused["jumps"][j0:j0 + T + 1], plain["jumps"][j0:j0 + T + 1]), (T, F)
+        n = int(plain["pl"][k])
+        assert int(fused["pl"][k]) == n and torch.equal(fused["pi"][p0:p0 + n], plain["pi"][p0:p0 + n]) and \
+            torch.equal(fused["pj"][p0:p0 + n], plain["pj"][p0:p0 + n]), (T, F)
+        assert float(fused["dist"][k]) == float(plain["dist"][k]), (T, F)
+        r = O.dtw_ref(a.reshape(T, F).cpu().numpy().astype(np.float64))
+        assert np.array_equal(fused["jumps"][j0:j0 + T + 1].cpu().numpy(), O.jumps_from_path(r.index1s, r.index2s)), (T, F)
+        n_small += int(T <= 64)
+    assert n_small > 60
+    # without WT_ALIGN_KEEP_COST the fused units leave no matrix behind, the others do; jumps are the same
+    lean = _align_units(shapes, dtype, 0, want_path=False)
+    assert torch.equal(lean["jumps"], plain["jumps"])
+    kept = [int(d["T"]) > 64 for d in lean["descs"]]
+    for d, k in zip(lean["descs"], kept):
+        c0, n = int(d["cost_offset"]), int(d["T"]) * int(d["F"])
+        if k:
+            assert torch.equal(lean["cost"][c0:c0 + n], plain["cost"][c0:c0 + n])
+    assert any(kept) and not all(kept)
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[1] size: 32 units of (8 heads, 224 tokens, 1500 frames).
     Size-independent properties + spot parity on 2 units."""

@@ -18,7 +18,11 @@ def _set(bench, dev, seed, n_chunks):
 
 
 def _snapshot(w):
-    return {k: w[k].clone() for k in ("result", "mel", "pad", "gmax", "cost")}
+    # (the cost buffer ends with the 16 bytes of read slack include/wtalign.h asks for: never written, not compared)
+    n_cost = max(int(d["cost_offset"]) + int(d["T"]) * int(d["F"]) for d in w["descs"])
+    snap = {k: w[k].clone() for k in ("result", "mel", "pad", "gmax")}
+    snap["cost"] = w["cost"][:n_cost].clone()
+    return snap
 
 
 @pytest.mark.parametrize("n_sets,n_chunks,steps", [(2, 32, 200), (3, 32, 210), (3, 5, 300)])
@@ -60,5 +64,5 @@ def test_batches_in_flight_on_distinct_streams(n_sets, n_chunks, steps):
                 if k < n_sets and j2 > k:
                     continue
                 for name, want in ref.items():
-                    assert torch.equal(w[name], want), f"step {k}: buffer set {j2}: {name} differs from its single-stream reference"
+                    assert torch.equal(w[name][:want.shape[0]], want), f"step {k}: buffer set {j2}: {name} differs from its single-stream reference"
                 assert torch.equal(w["host_result"], ref["result"].cpu())

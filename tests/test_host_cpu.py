@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.wt_version.restype = ctypes.c_int
-    assert L.wt_version() == _lib.ABI_VERSION == 2
+    assert L.wt_version() == _lib.ABI_VERSION == 3
 
 
 def test_seg_desc_layout_matches_header():

@@ -7,6 +7,7 @@
 #include <utility>
 
 #include "wt_common.h"
+#include "wt_small.h"
 
 namespace wt {
 
@@ -78,9 +79,11 @@ void scratch_forget_tags() {
 }
 
 int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, int, float, float *,
-               hipStream_t);
+               bool, hipStream_t);
 int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int, int32_t *, int32_t *, int32_t *, int32_t *,
-              double *, hipStream_t);
+              double *, bool, hipStream_t);
+int align_small(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, float, float *,
+                int32_t *, int32_t *, int32_t *, int32_t *, double *, hipStream_t);
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
                          hipStream_t);
 int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, int64_t, int64_t, int, int, int, float,
@@ -132,31 +135,55 @@ int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, i
 
 int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                   const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, void *stream) {
-    return wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost,
+    return wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, false,
                           (hipStream_t)stream);
 }
 
 int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
                  int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream) {
-    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist,
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist, false,
                          (hipStream_t)stream);
 }
 
 int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                          int step_pattern, int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist,
                          void *stream) {
-    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, step_pattern, jumps, path_i, path_j, path_len, dist,
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, step_pattern, jumps, path_i, path_j, path_len, dist, false,
+                         (hipStream_t)stream);
+}
+
+// Units that qualify for the fused small-unit kernel (wt_small.h: T <= 64 and the LDS they need; a property of the
+// unit's own shape) take it; the others take the batched kernels, which skip the small ones.
+int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+                      const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
+                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, int flags, void *stream) {
+    const bool fused = !(flags & WT_ALIGN_NO_FUSED_SMALL_UNITS);
+    bool any_small = false;
+    if (fused && segs_host && n_seg > 0)
+        for (int s = 0; s < n_seg && !any_small; ++s) any_small = wt::wt_small_unit(segs_host[s].T, segs_host[s].F);
+    // (argument checks: the batched entry points make them, also when every unit is small)
+    int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, any_small,
+                            (hipStream_t)stream);
+    if (rc) return rc;
+    if (!jumps || (!path_i != !path_j)) {
+        wt::set_error("wt_align_batch: null pointer or bad count");
+        return WT_E_BADARG;
+    }
+    if (any_small) {
+        rc = wt::align_small(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale,
+                             (flags & WT_ALIGN_KEEP_COST) ? cost : nullptr, jumps, path_i, path_j, path_len, dist,
+                             (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist, any_small,
                          (hipStream_t)stream);
 }
 
 int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                    const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream) {
-    int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost,
-                            (hipStream_t)stream);
-    if (rc) return rc;
-    return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist,
-                         (hipStream_t)stream);
+    return wt_align_batch_v3(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, jumps,
+                             path_i, path_j, path_len, dist, WT_ALIGN_KEEP_COST, stream);
 }
 
 int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps, int32_t *jumps_start,

@@ -1,0 +1,212 @@
+// Row-level core of the local-cost construction, shared by the batched kernels (wt_cost.hip: one wave per token row,
+// result to HBM) and the fused small-unit kernel (wt_small.hip: result stays in LDS for the DTW).  See wt_cost.hip for
+// the reference lines this restates.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "wt_common.h"
+
+namespace wt {
+
+__device__ __forceinline__ float ld_qk(const float *p) { return *p; }
+__device__ __forceinline__ float ld_qk(const __half *p) { return __half2float(*p); }
+
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// Asynchronous copy of one head's row (F logits) into dst[4 .. 4+F): HBM -> LDS directly (global_load_lds, no VGPR
+// round trip, completion tracked by vmcnt).
+// 16 bytes per lane and instruction (global_load_lds_dwordx4: lane l of a load lands at base + 16*l): a 1500-frame row
+// is 6 instructions instead of 24.  Groups of four floats that do not lie fully inside the row re-read the last full
+// group (their LDS slots are never used) -- except that the straddling group's slots hold the row's last F % 4
+// elements: those come through a register (`tail`, lanes 0..2) and are written by the caller once the row has landed.
+// Rows shorter than 4 frames take the dword form.  Returns this lane's tail element (meaningful for lane < F % 4).
+template <int C>
+__device__ __forceinline__ float stage_row(const float *__restrict__ src, float *dst, int F, int nch, int lane) {
+    if (F < 4) {   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + min(lane, F - 1)),
+                                         (__attribute__((address_space(3))) void *)(dst + 4), 4, 0, 2);
+        return 0.f;
+    }
+    const int nvec = F >> 2;
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        if (k * 256 < F) {  // wave-uniform
+            const int g = min(k * 64 + lane, nvec - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * g),
+                                             (__attribute__((address_space(3))) void *)(dst + 4 + k * 256), 16, 0,
+                                             2 /* cpol nt: every logit is read exactly once */);
+        }
+    }
+    return src[min(4 * nvec + lane, F - 1)];
+}
+// fp16 rows (a build-side storage option, BASELINE config 5) take the same road: the halves travel HBM -> LDS AS THEY
+// ARE (global_load_lds_dwordx4, 8 halves per lane and instruction: a 1500-frame row is 3 instructions) and are
+// converted on the way from LDS to registers.  The DMA wants a 4-byte aligned source: a row that starts on an odd
+// element is fetched from one element earlier (`sh` = 1: the same 4-byte word, i.e. inside the same tensor) and every
+// LDS index below carries that shift.  hs[8 + sh + f] = element f; only full groups of 8 halves inside [0, F + sh) are
+// copied, the last (F + sh) % 8 halves travel in a register (lanes 0..6) and are written once the row has landed,
+// like the fp32 tail.  Returns this lane's tail half (raw bits).
+template <int C>
+__device__ __forceinline__ unsigned short stage_row_h(const __half *__restrict__ src, unsigned short *hs, int F, int sh, int lane) {
+    const unsigned short *srcA = reinterpret_cast<const unsigned short *>(src) - sh;   // 4-byte aligned
+    const int Fh = F + sh;
+    const int nvec = Fh >> 3;
+#pragma unroll
+    for (int k = 0; k < (C + 7) / 8 + 1; ++k) {
+        const int g = k * 64 + lane;
+        if (g < nvec) {  // per lane: a lane without a full group neither reads nor writes (CAP is not a multiple of 512 halves)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA + 8 * g),
+                                             (__attribute__((address_space(3))) void *)(hs + 8 + k * 512), 16, 0,
+                                             2 /* cpol nt: every logit is read exactly once */);
+        }
+    }
+    return srcA[min(8 * nvec + lane, Fh - 1)];
+}
+
+// The head mean of one token row, before the division: acc[q] (+)= softmax_F(median9(row of head a)) for every selected
+// head a.  ONE WAVE; `lds` = this wave's two row buffers (double-buffered: head a+1 streams in while head a is being
+// consumed); everything else lives in registers.  row0 = the token's row of flat head 0 at the window's first frame.
+template <int C, typename QT>
+struct RowBuf {
+    static constexpr int CAP = C * 64;
+    static constexpr bool HALF = sizeof(QT) == 2;
+    // fp32: xs[4 + f] = element f (+ 4 halo slots each side).  fp16: raw halves, hs[8 + sh + f] = element f (sh = 0/1,
+    // see stage_row_h), + halo, + the qword the shifted register load over-reads.
+    static constexpr int BUF = HALF ? (CAP + 32) / 2 : CAP + 8;           // in floats (fp16: CAP + 32 halves)
+};
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int C, typename QT>
+__device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride, const int32_t *__restrict__ head_idx,
+                                             int n_heads, int F, float qk_scale, float (*lds)[RowBuf<C, QT>::BUF], int lane,
+                                             f2 (&acc)[C / 2]) {
+    constexpr bool HALF = RowBuf<C, QT>::HALF;
+    const int nch = (F + 63) >> 6;
+    // halo duty of lanes 0..7: scipy 'reflect' source index of positions -4..-1 and F..F+3
+    const int hpos = lane < 4 ? -(lane + 1) : F + (lane - 4);
+    const int hsrc = reflect_index(hpos, F);
+
+    // (re, re) pairs: the softmax tail below runs on packed fp32 instructions (v_pk_add/mul/fma_f32: two elements each)
+#pragma unroll
+    for (int q = 0; q < C / 2; ++q) acc[q] = (f2){0.f, 0.f};
+    // exp((w - max) * qk_scale) = exp2((w - max) * qk_scale * log2(e)): one constant (the host refuses qk_scale <= 0).
+    // The product is rounded once: half an ulp of the exponent, i.e. <= 1 ulp of the result for |w - max| < 2.9 and
+    // growing only where exp() itself vanishes from the softmax sum (measured against the compensated two-term
+    // product this kernel used before: same worst error against the oracle, 2.9e-7 of the matrix maximum; -7 % time)
+    const f2 cexp = (f2){qk_scale * 1.44269502162933349609375f, qk_scale * 1.44269502162933349609375f};
+
+    // fp32 rows: 16-byte LDS-DMA + a register for the last F % 4 elements; fp16 rows: the same with 8 halves per lane
+    const int tail0 = F & ~3, ntail = (!HALF && F >= 4) ? (F & 3) : 0;
+    // fp16: every head's row of this token starts at the same parity (head_stride elements apart: the shift is
+    // recomputed per head, it is one AND)
+    float tail = 0.f;
+    unsigned short tailh = 0;
+    int sh = 0;
+    auto stage = [&](int a) __attribute__((always_inline)) {
+        const QT *src = row0 + (int64_t)head_idx[a] * head_stride;
+        if constexpr (HALF) {
+            sh = (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 1);
+            tailh = stage_row_h<C>(src, reinterpret_cast<unsigned short *>(lds[a & 1]), F, sh, lane);
+        } else {
+            tail = stage_row<C>(src, lds[a & 1], F, nch, lane);
+        }
+    };
+    stage(0);
+    for (int a = 0; a < n_heads; ++a) {
+        float x[C + 8];
+        wait_vmcnt0();                 // head a's row has landed in LDS
+        wave_lds_fence();
+        if constexpr (HALF) {
+            unsigned short *hs = reinterpret_cast<unsigned short *>(lds[a & 1]);
+            const int Fh = F + sh;
+            if (lane < (Fh & 7)) hs[8 + (Fh & ~7) + lane] = tailh;   // (the group that straddles the end of the row)
+            wave_lds_fence();
+            if (lane < 8) {
+                const unsigned short hv = hs[8 + sh + hsrc];
+                hs[8 + sh + hpos] = hv;
+            }
+            wave_lds_fence();
+            // this lane's C + 8 elements start at half 4 + sh + lane * C: read the dwords from half 4 + lane * C (8-byte
+            // aligned) and, for odd starts, funnel-shift neighbouring dwords by one half
+            constexpr int NQ = (C + 8) / 4 + 1;
+            const uint2 *qp = reinterpret_cast<const uint2 *>(hs + 4 + lane * C);
+            unsigned w[2 * NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const uint2 r = qp[k];
+                w[2 * k] = r.x; w[2 * k + 1] = r.y;
+            }
+            const bool odd = sh != 0;   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < (C + 8) / 2; ++k) {
+                const unsigned v = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 16) : w[k];
+                const __half2 h2 = *reinterpret_cast<const __half2 *>(&v);
+                const float2 f2v = __half22float2(h2);
+                x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
+            }
+        } else {
+            float *xs = lds[a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+            if (lane < ntail) xs[4 + tail0 + lane] = tail;   // (the group that straddles the end of the row)
+            wave_lds_fence();
+            if (lane < 8) {
+                const float hv = xs[4 + hsrc];
+                xs[4 + hpos] = hv;
+            }
+            wave_lds_fence();
+            const float4 *xp = reinterpret_cast<const float4 *>(xs + lane * C);
+#pragma unroll
+            for (int k = 0; k < (C + 8) / 4; ++k) {
+                const float4 r = xp[k];
+                x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
+            }
+        }
+        // Row a now lives in registers: start streaming head a+1 into the other buffer; it lands while
+        // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
+        // that follows an LDS-DMA, which would serialise the copy with the reads.)
+        if (a + 1 < n_heads) stage(a + 1);
+        // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
+        float lo[C + 6], mi[C + 6], hi[C + 6];
+#pragma unroll
+        for (int p = 0; p < C + 6; ++p) {
+            lo[p] = min3f(x[p], x[p + 1], x[p + 2]);
+            mi[p] = med3f(x[p], x[p + 1], x[p + 2]);
+            hi[p] = max3f(x[p], x[p + 1], x[p + 2]);
+        }
+        float m[C];
+        float mx = -1e30f;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const float med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
+                                    min3f(hi[q], hi[q + 3], hi[q + 6]));
+            const bool ok = (lane * C + q) < F;
+            m[q] = ok ? med : -1e30f;
+            mx = fmaxf(mx, m[q]);
+        }
+        mx = wave_max_dpp(mx);
+        const f2 mx2 = (f2){mx, mx};
+        f2 e[C / 2];
+        f2 s2 = (f2){0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) {
+            const f2 t = ((f2){m[2 * q], m[2 * q + 1]} - mx2) * cexp;
+            e[q] = (f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // (masked: exp2(-1.4e30) = 0)
+            s2 += e[q];
+        }
+        const float s = wave_sum_dpp(s2.x + s2.y);
+        const float inv = 1.0f / s;
+        const f2 inv2 = (f2){inv, inv};
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) acc[q] = __builtin_elementwise_fma(e[q], inv2, acc[q]);
+    }
+
+}
+
+// mean over heads (torch CPU: sum then div): x * (1/n) == x / n exactly for a power of two
+__device__ __forceinline__ float head_mean(float sum, int n_heads) {
+    const float nh = (float)n_heads;
+    return ((n_heads & (n_heads - 1)) == 0) ? sum * (1.0f / nh) : sum / nh;
+}
+
+}  // namespace wt

@@ -37,13 +37,11 @@
 // F+T-cell dependency chain; throughput comes from the batch.
 #include <algorithm>
 #include <mutex>
-#include <type_traits>
 
-#include "wt_common.h"
+#include "wt_dtw_core.h"
+#include "wt_small.h"
 
 namespace wt {
-
-constexpr int BLK = 32;  // steps per block = bits per direction word
 
 #ifdef WT_PROBE  // tools/probes/dtw_probe.hip only: per-wave timestamps (s_memtime) of unit 0
 __device__ long long wt_probe_clk[16];
@@ -84,24 +82,6 @@ __host__ __device__ inline int dtw_blocks(int F) { return (F + 63 + BLK - 1) / B
 __host__ __device__ inline int dtw_bnd_pitch(int F) { return (F + 64 + BLK + 1) & ~1; }      // doubles per boundary row (even: 16-byte rows)
 constexpr int DUMP = 64 + BLK;  // doubles per producer wave: where lanes 0..62 park the per-step store only lane 63 needs
 
-// in-place wave_shr:1 -- lane 0 keeps what `up` already holds (its +inf)
-__device__ __forceinline__ void shift_in(double &up, double g) {
-    union { double d; int i[2]; } s, o;
-    s.d = g;
-    o.d = up;
-    o.i[0] = __builtin_amdgcn_update_dpp(o.i[0], s.i[0], 0x138, 0xf, 0xf, false);
-    o.i[1] = __builtin_amdgcn_update_dpp(o.i[1], s.i[1], 0x138, 0xf, 0xf, false);
-    up = o.d;
-}
-
-// wa = 2wa + (a1 < a2), wb = 2wb + (b1 < b2): a compare into VCC and an add-with-carry per plane (hipcc emits
-// cndmask + shift + or instead).  ONE asm statement for both planes: between two separate statements hipcc's hazard
-// recogniser, blind to their contents, puts an s_nop that costs the wave a whole issue slot every step.
-__device__ __forceinline__ void plane_bits(uint32_t &wa, uint32_t &wb, double a1, double a2, double b1, double b2) {
-    asm volatile("v_cmp_lt_f64 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
-                 "v_cmp_lt_f64 vcc, %4, %5\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
-                 : "+v"(wa), "+v"(wb) : "v"(a1), "v"(a2), "v"(b1), "v"(b2) : "vcc");
-}
 // The two plane words of a finished block -> the unit's scratch slot: ONE 8-byte buffer store per lane on a descriptor
 // of the slot (base = the unit's first plane word, range = its slot): the compiler sees the store (it keeps its own
 // vmcnt / hazard bookkeeping -- round 2 issued it as inline assembly behind the compiler's back) and the hardware
@@ -117,54 +97,16 @@ __device__ __forceinline__ uint2 load_plane_words(__amdgpu_buffer_rsrc_t slot, i
     return make_uint2(v.x, v.y);
 }
 
-// One 32-step block of the anti-diagonal sweep.
-// EDGE: this wave has a producer wave above it; edge[k] = g[64w-1, s0+k] (the same value in every lane, read from
-// the boundary row with broadcast LDS loads before the block) becomes the "old" operand of the wave_shr:1 that
-// delivers g[i-1,*], i.e. what lane 0 receives -- no rotation, no copy: 2 DPP moves per step like the first wave.
-// PUBLISH: a consumer wave below; every lane stores its `best` of step k at pub[k] -- lane 63's pointer walks the
-// boundary row, the other lanes' pointers sit in a 64+32-double parking area (distinct addresses: no bank
-// conflict, no exec juggling) -- one ds_write per step instead of a 4-DPP cross-lane shift register.
-// u0/u1 alternate as "g[i-1,j]" and "g[i-1,j-1]" so that no register is copied.
-// FIRST: the block that holds step 0 on the first wave.  Cell (0,0) is seeded through lane 0's `diag` (u1 = 0.0, so
-// that p1 = 0 + lm[0,0] = cm[0,0] as in computeCM); wave_shr:1 never overwrites lane 0, so that seed must be
-// retired to +inf before u1 comes back as "g[-1, 1]" at step 1 -- two moves, once per unit, none in the steady loop.
-// NOUP: the reference's other step pattern (T.py:1575-1580, subwords_can_be_empty=False): "symmetric1 without the
-// possibility to have the same timestamp for two tokens" = candidates p1 (diagonal) and p2 (same token, previous frame)
-// only; the previous-token/same-frame candidate never exists, so its plane bit is never set.
-template <bool EDGE, bool PUBLISH, bool DIST, bool FIRST = false, bool NOUP = false>
-__device__ __forceinline__ void sweep_block(const float (&cur)[BLK], double &g, double &u0, double &u1,
-                                            const double (&edge)[BLK], uint32_t &wa, uint32_t &wb, double *pub, int s0,
-                                            int sfinal, double &gfinal) {
-#pragma unroll
-    for (int k = 0; k < BLK; ++k) {
-        double &up = (k & 1) ? u1 : u0;          // g[i-1, j]   (written now)
-        const double diag = (k & 1) ? u0 : u1;   // g[i-1, j-1] (written one step ago)
-        if (FIRST && k == 1) u1 = __builtin_inf();   // (lanes > 0 receive their neighbour's g just below)
-        if (EDGE) up = wave_shr1(g, edge[k]);    // lane 0 <- edge value of this step, lane l <- g of lane l-1
-        else shift_in(up, g);                    // lane 0 keeps its +inf
-        const double c = (double)cur[k];
-        const double p1 = diag + c;
-        const double p2 = g + c;
-        const double p3 = NOUP ? __builtin_inf() : up + c;
-        const double m12 = __builtin_fmin(p1, p2);
-        const double best = __builtin_fmin(m12, p3);
-        // plane A: "same token, previous frame" beats the diagonal; plane B: "previous token, same frame" beats both
-        plane_bits(wa, wb, p2, p1, p3, m12);
-        g = best;
-        if (PUBLISH) pub[k] = best;
-        if (DIST && s0 + k == sfinal) gfinal = best;
-    }
-}
-
 template <bool DIST, bool TINY, bool NOUP>
 __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_seg_desc *__restrict__ segs, int32_t *__restrict__ jumps,
                            int32_t *__restrict__ path_i, int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
-                           double *__restrict__ dist, uint2 *planes, long long plane_stride) {
+                           double *__restrict__ dist, uint2 *planes, long long plane_stride, int skip_small) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const wt_seg_desc d = segs[blockIdx.x];
     const int T = d.T, F = d.F;
     const int nw = blockDim.x >> 6;
     if ((T + 63) / 64 != nw) return;  // block-uniform: unit belongs to another launch class
+    if (skip_small && wt_small_unit(T, F)) return;   // (wt_align_batch: the fused small-unit kernel owns this unit)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lives in an SGPR
@@ -275,89 +217,11 @@ __global__ __launch_bounds__(256) void dtw_kernel(const float *cost, const wt_se
     if (wave != 0) return;
     WT_STAMP(8);
 
-    // ---- backtrack (dtw/_backtrack.py) + jumps (transcribe.py:1648-1652) ----
-    // step s of row r sits at bit (31 - (s & 31)) of word s >> 5:  A=1,B=0 -> dir 2; B=1 -> dir 3; else dir 1.
-    // The walk is a chain of dependent steps on ONE wave, so what it must avoid is an LDS round trip (and taken
-    // branches) per row.  Lane l loads the two plane words around the current step index for row bi - l (a 64-step
-    // window: consecutive rows of a 64-row group move left by a few steps each, so one window serves several rows);
-    // the walk itself runs on the scalar unit: v_readlane of that row's words, one 64-bit "first cell at or below
-    // this step that is not direction 2" (s_ff1_i32_b64), and the row's jump goes into lane (row & 63) of one
-    // VGPR; each 64-row group leaves with one coalesced store.  A new window is loaded only when the walk leaves it.
-    int32_t *jp = jumps + d.jumps_offset;
-    int bi = T - 1;
-    int r = bi & 63;
-    int s = F - 1 + r;   // step index of the current cell = frame + (row & 63)
-    int ups = 0;         // direction-3 moves: path length = F + ups
-    int jv = 0;
-    while (bi > 0) {
-        // window: words win, win + 1 of rows bi, bi - 1, ... (lane l: row bi - l)
-        const int win = max((s >> 5) - 1, 0);
-        const int base = 32 * win;
-        const int top = bi;
-        const int rowp = 8 * (win * rowsP + max(bi - lane, 0));                // lanes read consecutive rows: coalesced
-        const uint2 w0 = load_plane_words(pbuf, rowp), w1 = load_plane_words(pbuf, rowp + 8 * rowsP);
-        const int a0 = (int)w0.x, b0 = (int)w0.y, a1 = (int)w1.x, b1 = (int)w1.y;
-        bool more;
-        do {   // one row per iteration, no memory access, one taken branch
-            const int sel = top - bi;
-            const uint64_t A = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(a0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane(a1, sel);
-            const uint64_t B = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(b0, sel) << 32) | (uint32_t)__builtin_amdgcn_readlane(b1, sel);
-            // cells at window positions <= s - base (bit 63 - position) that are NOT direction 2
-            const uint64_t stop = (~A | B) & (~0ull << (base + 63 - s));
-            if (__builtin_expect(stop == 0, 0)) {   // direction 2 down to the window's edge: go on in the words below
-                s = base - 1;
-                break;
-            }
-            const int bit = __builtin_ctzll(stop);
-            s = base + 63 - bit;                              // the cell where the path leaves the row
-            jv = (lane == r) ? s - r : jv;                    // jumps[bi] = its frame
-            const int up = (int)(B >> bit) & 1;               // dir 3: previous token, same frame; dir 1: diagonal
-            ups += up;
-            s += up - 2;                                      // frame -= !up, row & 63 -= 1
-            --r;
-            --bi;
-            more = ((s - base) | r | (bi - 1)) >= 0;      // still inside the window, the row group and the matrix
-        } while (more);
-        if (r < 0) {                                          // left a 64-row group: rows bi+1 .. bi+64
-            if (bi + 1 + lane < T) jp[bi + 1 + lane] = jv;
-            r = 63;
-            s += 64;
-        }
-    }
-    const int len = F + ups;
-    if (lane > 0 && lane < T) jp[lane] = jv;
-    if (lane == 0) {
-        jp[0] = 0;
-        jp[T] = F - 1;
-        if (path_len) path_len[blockIdx.x] = len;
-    }
+    // ---- backtrack + jumps (wt_dtw_core.h) ----
+    backtrack_unit([&](int k) { return load_plane_words(pbuf, 8 * k); }, T, F, rowsP, lane, (int)blockIdx.x,
+                   jumps + d.jumps_offset, (path_i && path_j) ? path_i + d.path_offset : nullptr,
+                   (path_i && path_j) ? path_j + d.path_offset : nullptr, path_len);
     WT_STAMP(9);
-    if (path_i && path_j) {
-        int32_t *pi = path_i + d.path_offset, *pj = path_j + d.path_offset;
-        int bj = F - 1;
-        bi = T - 1;
-        int pos = len - 1;
-        int have = -1;        // which (block, row) word pair is cached: the walk stays in a word for up to 32 steps
-        uint32_t ca = 0, cb = 0;
-        while (true) {
-            if (lane == 0) { pi[pos] = bi; pj[pos] = bj; }
-            if (bi == 0 && bj == 0) break;
-            if (bi == 0) { --bj; --pos; continue; }
-            const int s = bj + (bi & 63);
-            const int key = (s >> 5) * rowsP + bi;
-            if (key != have) {
-                const uint2 AB = load_plane_words(pbuf, 8 * key);
-                ca = __builtin_amdgcn_readfirstlane(AB.x);
-                cb = __builtin_amdgcn_readfirstlane(AB.y);
-                have = key;
-            }
-            const int bit = 31 - (s & 31);
-            const uint32_t a = (ca >> bit) & 1u;
-            const uint32_t b = (cb >> bit) & 1u;
-            if (b) { --bi; } else if (a) { --bj; } else { --bi; --bj; }
-            --pos;
-        }
-    }
 }
 
 static size_t dtw_plane_words(int nw, int F) { return (size_t)nw * 64 * dtw_blocks(F); }   // uint2 per unit slot
@@ -370,7 +234,8 @@ int scratch_dtw(hipStream_t st, size_t bytes, void **out);   // the direction pl
 
 template <bool DIST, bool TINY, bool NOUP>
 static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, int32_t *jumps,
-                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes, hipStream_t st) {
+                      int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes, int skip_small,
+                      hipStream_t st) {
     // function attributes are per (instantiation, device): set the first time each device launches this one
     static std::mutex mu;
     static bool attr_set[64] = {false};
@@ -393,7 +258,7 @@ static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg,
         const size_t lds = dtw_lds_bytes(nw, maxF[nw]);
         // (the launches of one call run one after the other on the stream: they share the plane slots)
         hipLaunchKernelGGL((dtw_kernel<DIST, TINY, NOUP>), dim3(n_seg), dim3(64 * nw), lds, st, cost, segs_dev, jumps, path_i,
-                           path_j, path_len, dist, planes, (long long)dtw_plane_words(nw, maxF[nw]));
+                           path_j, path_len, dist, planes, (long long)dtw_plane_words(nw, maxF[nw]), skip_small);
     }
     WT_HIP(hipGetLastError());
     return WT_OK;
@@ -402,16 +267,17 @@ static int launch_dtw(const float *cost, const wt_seg_desc *segs_dev, int n_seg,
 template <bool NOUP>
 static int launch_all(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int *maxF, const int *maxFt,
                       int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, uint2 *planes,
-                      hipStream_t st) {
-    int rc = dist ? launch_dtw<true, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st)
-                  : launch_dtw<false, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, st);
+                      int skip_small, hipStream_t st) {
+    int rc = dist ? launch_dtw<true, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, skip_small, st)
+                  : launch_dtw<false, false, NOUP>(cost, segs_dev, n_seg, maxF, jumps, path_i, path_j, path_len, dist, planes, skip_small, st);
     if (rc) return rc;
-    return dist ? launch_dtw<true, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
-                : launch_dtw<false, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
+    return dist ? launch_dtw<true, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, skip_small, st)
+                : launch_dtw<false, true, NOUP>(cost, segs_dev, n_seg, maxFt, jumps, path_i, path_j, path_len, dist, planes, skip_small, st);
 }
 
 int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int step_pattern,
-              int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+              int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, bool skip_small,
+              hipStream_t st) {
     if (!cost || !segs_host || !segs_dev || !jumps || n_seg < 0 || (!path_i != !path_j)) {
         set_error("wt_dtw_batch: null pointer or bad count");
         return WT_E_BADARG;
@@ -428,6 +294,7 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
             set_error("wt_dtw_batch: unit %d has unsupported shape T=%d F=%d", s, d.T, d.F);
             return WT_E_UNSUPPORTED;
         }
+        if (skip_small && wt_small_unit(d.T, d.F)) continue;   // (its kernels skip it too)
         const int nw = (d.T + 63) / 64;
         int *mf = (d.F < 4 || d.T * d.F < 36) ? maxFt : maxF;
         if (d.F > mf[nw]) mf[nw] = d.F;
@@ -441,12 +308,13 @@ int dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc
         if (maxF[nw]) slot = std::max(slot, dtw_plane_words(nw, maxF[nw]));
         if (maxFt[nw]) slot = std::max(slot, dtw_plane_words(nw, maxFt[nw]));
     }
+    if (slot == 0) return WT_OK;   // (every unit belongs to the fused small-unit kernel)
     uint2 *planes = nullptr;
     int rc = scratch_dtw(st, (size_t)n_seg * slot * sizeof(uint2), (void **)&planes);
     if (rc) return rc;
     return step_pattern == WT_STEP_SYMMETRIC1
-               ? launch_all<false>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, st)
-               : launch_all<true>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, st);
+               ? launch_all<false>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, skip_small ? 1 : 0, st)
+               : launch_all<true>(cost, segs_dev, n_seg, maxF, maxFt, jumps, path_i, path_j, path_len, dist, planes, skip_small ? 1 : 0, st);
 }
 
 }  // namespace wt

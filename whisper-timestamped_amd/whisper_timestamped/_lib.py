@@ -30,9 +30,10 @@ assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
-           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern"]
+           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
+WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS = 1, 2
 
 
 class WtError(RuntimeError):
@@ -58,6 +59,7 @@ def load():
     L.wt_cost_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp]
     L.wt_dtw_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.wt_align_batch.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
+    L.wt_align_batch_v3.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, i32, vp]
     L.wt_find_start_padding_batch.argtypes = [vp, i32, i32, i32, vp, vp]
     L.wt_disfluency_batch.argtypes = [vp, vp, i32, vp, vp, ctypes.c_double, ctypes.c_double, vp]
     L.wt_logprob_gather_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, i32, vp, vp]
@@ -254,15 +256,15 @@ def dtw_batch(cost: torch.Tensor, descs: np.ndarray, descs_dev: torch.Tensor, ju
 
 
 def align_batch(qk, descs, descs_dev, head_idx, cost, jumps, path_i=None, path_j=None, path_len=None, dist=None,
-                medfilt_width: int = 9, qk_scale: float = 1.0):
+                medfilt_width: int = 9, qk_scale: float = 1.0, flags: int = WT_ALIGN_KEEP_COST):
     _need_cuda(qk, "qk")
     same_device(qk, descs_dev, head_idx, cost, jumps, path_i, path_j, path_len, dist)
     dt = {torch.float32: WT_DTYPE_F32, torch.float16: WT_DTYPE_F16}[qk.dtype]
     with on_device(qk) as st:
-        rc = load().wt_align_batch(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
-                                   head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), jumps.data_ptr(), _ptr(path_i),
-                                   _ptr(path_j), _ptr(path_len), _ptr(dist), st)
-    _check(rc, "wt_align_batch")
+        rc = load().wt_align_batch_v3(qk.data_ptr(), dt, descs.ctypes.data, descs_dev.data_ptr(), len(descs), head_idx.data_ptr(),
+                                      head_idx.numel(), medfilt_width, qk_scale, cost.data_ptr(), jumps.data_ptr(), _ptr(path_i),
+                                      _ptr(path_j), _ptr(path_len), _ptr(dist), int(flags), st)
+    _check(rc, "wt_align_batch_v3")
 
 
 def find_start_padding(mel: torch.Tensor) -> torch.Tensor:

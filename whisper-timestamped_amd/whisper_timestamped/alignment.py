@@ -320,11 +320,15 @@ class AlignmentBatch:
                 self.dist = torch.empty(n_units, dtype=torch.float64, device=dev)
             L = _lib.load()
             if self.step_pattern == _lib.WT_STEP_SYMMETRIC1:
-                rc = L.wt_align_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
-                                      n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
-                                      cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
-                                      _lib._ptr(self.path_len), _lib._ptr(self.dist), stream)
-                _lib._check(rc, "wt_align_batch")
+                # units of the reference's per-segment shape take the fused small-unit kernel; their cost matrices only
+                # go to HBM when somebody reads them afterwards (keep_cost, the disfluency kernel)
+                flags = (_lib.WT_ALIGN_KEEP_COST if (self.keep_cost or disfl) else 0) | \
+                    (0 if FUSED_SMALL_UNITS else _lib.WT_ALIGN_NO_FUSED_SMALL_UNITS)
+                rc = L.wt_align_batch_v3(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
+                                         n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
+                                         cost.data_ptr(), jumps.data_ptr(), _lib._ptr(self.path_i), _lib._ptr(self.path_j),
+                                         _lib._ptr(self.path_len), _lib._ptr(self.dist), flags, stream)
+                _lib._check(rc, "wt_align_batch_v3")
             else:
                 rc = L.wt_cost_batch(base, {torch.float32: 0, torch.float16: 1}[dt], descs.ctypes.data, descs_dev.data_ptr(),
                                      n_units, slot.heads(n_sel).data_ptr(), n_sel, self.medfilt_width, float(self.qk_scale),
@@ -414,6 +418,7 @@ class AlignmentBatch:
         return self.path_i[p0:p0 + n], self.path_j[p0:p0 + n]
 
 
+FUSED_SMALL_UNITS = True      # False: every unit through the batched kernels (measurements, tests)
 DISFLUENCY_MIN_PROMINENCE, DISFLUENCY_MIN_WIDTH = 0.02, 3.0      # find_peaks arguments of transcribe.py:1663-1666
 
 
