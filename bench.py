@@ -225,9 +225,9 @@ def _stage_calls(w):
                                    w["jumps"].data_ptr(), 0, 0, 0, 0, st), "wt_dtw_batch")
 
     if w.get("align") == "fused":
-        # ONE entry point for cost + DTW (wt_align_batch_v3): units of the per-segment shape take the fused small-unit
-        # kernel (cost, DTW, backtrack in one workgroup, the matrix stays in LDS), the others the batched kernels.  The
-        # whole of it is timed as the "cost" stage; the "dtw" stage is empty.
+        # ONE entry point for cost + DTW (wt_align_batch_v3): after the batched row pass, units of the per-segment shape
+        # take the fused tail kernel (column norm, cost[0,0], DTW, backtrack in one workgroup, the matrix in LDS), the
+        # others the batched kernels.  The whole of it is timed as the "cost" stage; the "dtw" stage is empty.
         def cost(st):   # noqa: F811
             _lib._check(L.wt_align_batch_v3(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data,
                                             w["descs_dev"].data_ptr(), n_units, w["head_idx"].data_ptr(), cfg["A"], 9, 1.0,
@@ -345,17 +345,15 @@ def run_step(w, ev=None, streams=None):
 
 
 def algorithmic_bytes(cfg, fused=False):
-    """Per launch (= per step on one rank), SURVEY.md 8(d).  fused: the small units' matrices never reach HBM (the units
-    that do not qualify still write and re-read theirs: counted)."""
+    """Per launch (= per step on one rank), SURVEY.md 8(d)."""
     n, A, V, M = cfg["n_chunks"], cfg["A"], cfg["V"], cfg["n_mels"]
     units = cfg.get("units") or [(cfg["T"], cfg["F"])] * n
     s_in = 2 if cfg.get("qk_dtype") == "f16" else 4
     tf = sum(t * f for t, f in units)
     rows = sum(t for t, _ in units)
-    if fused:
-        big = sum(t * f for t, f in units if t > 64)          # (T <= 64 is the dominant condition of wt_small_unit)
+    if fused:   # the same bytes as the two stages below, moved by one entry point and timed as one stage
         return {"logmel": n * (480000 * 4 + M * 3000 * 4), "padding": n * M * 4,
-                "cost": A * tf * s_in + 2 * big * 4 + 4 * (rows + len(units)), "dtw": 0, "logprob": rows * (V * 4 + 8)}
+                "cost": A * tf * s_in + 2 * tf * 4 + 4 * (rows + len(units)), "dtw": 0, "logprob": rows * (V * 4 + 8)}
     return {
         "logmel": n * (480000 * 4 + M * 3000 * 4),
         "padding": n * M * 4,                               # an unpadded window is decided by its last column
@@ -863,7 +861,7 @@ def role_kernel(args):
                                      "path enumeration and on transformers' DTW for tie-free inputs)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
-                       "alignment_entry": "wt_align_batch_v3 (fused small-unit kernel + batched kernels; timed as the cost stage)"
+                       "alignment_entry": "wt_align_batch_v3 (batched row pass + fused small-unit tail kernel; timed as the cost stage)"
                                           if w.get("align") == "fused" else "wt_cost_batch + wt_dtw_batch",
                        "rccl_ranks_seen": ranks_seen,
                        "result_gather": f"{'gloo (dry run)' if dry else 'rccl'} gather to rank 0, one message per {args.gather_every} steps"

@@ -156,11 +156,11 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
 
 /* wt_cost_batch followed by wt_dtw_batch on the same stream = perform_word_alignment's numerics (T.py:1540-1581,
  * 1648-1652) for a batch of units.  Units with T <= 64 whose (T, F) matrix fits a workgroup's LDS -- the reference's
- * default per-segment call shape (T.py:544-557: T p50 11, F p50 144) -- are aligned by ONE fused kernel (cost, DTW and
- * backtrack in one workgroup, the matrix never leaves LDS); which path a unit takes depends on its own shape only, and
- * cost / jumps are bit-identical on both.
- *   flags : WT_ALIGN_KEEP_COST             cost[] is written for every unit (without it only the units of the
- *                                          batched kernels leave their matrix there); wt_disfluency_batch needs it
+ * default per-segment call shape (T.py:544-557: T p50 11, F p50 144) -- leave the batched kernels after the row pass:
+ * ONE fused kernel does their column norm, cost[0,0], DTW and backtrack in one workgroup with the matrix in LDS; which
+ * path a unit takes depends on its own shape only, and cost / jumps are bit-identical on both.
+ *   flags : WT_ALIGN_KEEP_COST             cost[] holds the final matrix of every unit (without it the small units
+ *                                          leave only their head-mean rows there); wt_disfluency_batch needs it
  *           WT_ALIGN_NO_FUSED_SMALL_UNITS  every unit through the batched kernels (A/B measurements, tests)
  * wt_align_batch(...) = wt_align_batch_v3(..., WT_ALIGN_KEEP_COST, stream). */
 #define WT_ALIGN_KEEP_COST 1

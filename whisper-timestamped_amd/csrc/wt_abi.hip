@@ -82,8 +82,8 @@ int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int,
                bool, hipStream_t);
 int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int, int32_t *, int32_t *, int32_t *, int32_t *,
               double *, bool, hipStream_t);
-int align_small(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, float, float *,
-                int32_t *, int32_t *, int32_t *, int32_t *, double *, hipStream_t);
+int align_small_tail(const wt_seg_desc *, const wt_seg_desc *, int, float *, bool, int32_t *, int32_t *, int32_t *, int32_t *,
+                     double *, hipStream_t);
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
                          hipStream_t);
 int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, int64_t, int64_t, int, int, int, float,
@@ -152,8 +152,9 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
                          (hipStream_t)stream);
 }
 
-// Units that qualify for the fused small-unit kernel (wt_small.h: T <= 64 and the LDS they need; a property of the
-// unit's own shape) take it; the others take the batched kernels, which skip the small ones.
+// rowmean for every unit; then the units that qualify (wt_small.h: T <= 64 and the LDS they need; a property of the
+// unit's own shape) take the fused tail kernel -- column norm, cost[0,0], DTW and backtrack in one workgroup -- and the
+// others colnorm / fix00 / dtw, which skip the small ones.
 int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                       const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, int flags, void *stream) {
@@ -170,9 +171,8 @@ int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host
         return WT_E_BADARG;
     }
     if (any_small) {
-        rc = wt::align_small(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale,
-                             (flags & WT_ALIGN_KEEP_COST) ? cost : nullptr, jumps, path_i, path_j, path_len, dist,
-                             (hipStream_t)stream);
+        rc = wt::align_small_tail(segs_host, segs_dev, n_seg, cost, (flags & WT_ALIGN_KEEP_COST) != 0, jumps, path_i, path_j,
+                                  path_len, dist, (hipStream_t)stream);
         if (rc) return rc;
     }
     return wt::dtw_batch(cost, segs_host, segs_dev, n_seg, WT_STEP_SYMMETRIC1, jumps, path_i, path_j, path_len, dist, any_small,

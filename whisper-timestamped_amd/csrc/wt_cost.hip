@@ -37,7 +37,7 @@ template <int C, typename QT, bool EXACT>
 __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                       const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
                                                       float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
-                                                      int f_lo, int f_hi, int skip_small) {
+                                                      int f_lo, int f_hi) {
     constexpr int CAP = C * 64;
     constexpr int BUF = RowBuf<C, QT>::BUF;                        // per wave: double-buffered row (wt_cost_core.h)
     __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];
@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     const int F = d.F;
     const int t = blockIdx.x * 4 + wave;
     if (F <= f_lo || F > f_hi || t >= d.T) return;  // wave-uniform; the host guarantees f_hi <= CAP
-    if (skip_small && wt_small_unit(d.T, F)) return;   // (wt_align_batch: the fused small-unit kernel owns this unit)
     if (EXACT) __builtin_assume(F > (C - 4) * 64);
     if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
 
@@ -172,11 +171,10 @@ struct ClassRange {
     int lo = 0, n = 0, maxT = 0, maxF = 0;
     bool any = false;
 };
-static bool class_ranges(const wt_seg_desc *segs_host, int n_seg, ClassRange (&cls)[7], bool skip_small) {
+static bool class_ranges(const wt_seg_desc *segs_host, int n_seg, ClassRange (&cls)[7]) {
     bool grouped = true;
     int last = -1;
     for (int i = 0; i < n_seg; ++i) {
-        if (skip_small && wt_small_unit(segs_host[i].T, segs_host[i].F)) continue;   // (its kernels skip it too)
         const int c = (segs_host[i].F + 255) / 256 - 1;
         ClassRange &r = cls[c];
         if (!r.any) { r.any = true; r.lo = i; }
@@ -231,7 +229,7 @@ static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2], bool &co
 template <typename QT>
 static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, const LaunchGroup *groups, int n_groups,
                           bool grouped, const int32_t *head_idx, int n_heads, float qk_scale, float *cost,
-                          unsigned *segstate, int skip_small, hipStream_t st) {
+                          unsigned *segstate, hipStream_t st) {
     for (int k = 0; k < n_groups; ++k) {
         const LaunchGroup &g = groups[k];
         const dim3 grid((g.maxT + 3) / 4, grouped ? g.n : n_seg);
@@ -240,10 +238,10 @@ static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, 
     case CI:                                                                                                         \
         if (g.f_lo == CI * 256)                                                                                      \
             hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT, true>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, \
-                               n_heads, qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi, skip_small);                 \
+                               n_heads, qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi);                             \
         else                                                                                                         \
             hipLaunchKernelGGL((rowmean_kernel<4 * (CI + 1), QT, false>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, \
-                               n_heads, qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi, skip_small);                 \
+                               n_heads, qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi);                             \
         break;
         switch (g.ci) {
             WT_LAUNCH_ROWMEAN(0)
@@ -289,23 +287,27 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     int rc = scratch(st, (size_t)n_seg * sizeof(unsigned), (void **)&segstate);
     if (rc) return rc;
     ClassRange cls[7];
-    bool grouped = class_ranges(segs_host, n_seg, cls, skip_small);
+    bool grouped = class_ranges(segs_host, n_seg, cls);
     LaunchGroup groups[2];
     const int n_groups = plan_groups(cls, groups, grouped);
-    if (n_groups == 0) return WT_OK;   // (every unit belongs to the fused small-unit kernel)
     const int skip = skip_small ? 1 : 0;
     // the two groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
-                            segstate, skip, st);
+                            segstate, st);
     else if (qk_dtype == WT_DTYPE_F16)
         rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
-                            segstate, skip, st);
+                            segstate, st);
     else {
         set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
         return WT_E_BADARG;
     }
     if (rc) return rc;
+    // wt_align_batch: the column pass of the small units belongs to the fused tail kernel (wt_small.hip); the kernels
+    // below skip them, and are not launched at all for a batch of small units only
+    bool any_big = !skip_small;
+    for (int i = 0; i < n_seg && !any_big; ++i) any_big = !wt_small_unit(segs_host[i].T, segs_host[i].F);
+    if (!any_big) return WT_OK;
     if (grouped) {
         for (int k = 0; k < n_groups; ++k)
             hipLaunchKernelGGL(colnorm_kernel, dim3((groups[k].maxF + 63) / 64, (groups[k].n + 7) & ~7), dim3(64 * CN_WAVES), 0, st,

@@ -1,4 +1,4 @@
-// Which alignment units take the fused small-unit kernel (wt_small.hip), and what it needs of LDS.  Pure functions of a
+// Which alignment units take the fused small-unit tail kernel (wt_small.hip), and what it needs of LDS.  Pure functions of a
 // unit's own (T, F) -- host and device agree, and the same unit takes the same path in any batch.
 #pragma once
 #include "wt_common.h"
@@ -16,24 +16,14 @@ __host__ __device__ inline int wt_small_pitch(int T, int F) {
     if ((p & 4) == 0) p += 4;
     return p;
 }
-// elements per lane of the row instantiation that serves F (4, 8, 16 or 28: wt_small.hip's four groups)
-__host__ __device__ inline int wt_small_c(int F) { return F <= 256 ? 4 : F <= 512 ? 8 : F <= 1024 ? 16 : 28; }
-// row staging of the cost phase (4 waves x 2 buffers of the fp32 size: the fp16 buffers are smaller and use the same
-// budget), reused by the direction planes of the DTW phase (>= 2 blocks of 64 word pairs)
-__host__ __device__ inline int wt_small_stage_bytes(int F) {
-    const int stage = 4 * 2 * (wt_small_c(F) * 64 + 8) * 4;
-    return stage;
-}
+// direction planes of the DTW phase (>= 2 blocks of 64 word pairs)
 __host__ __device__ inline int wt_small_plane_bytes(int T, int F) {
     int blocks = (F + T - 1 + 31) / 32 + 1;
     if (blocks < 2) blocks = 2;
     return blocks * 64 * 8;
 }
 __host__ __device__ inline long long wt_small_lds_bytes(int T, int F) {
-    int a = wt_small_stage_bytes(F);
-    const int pl = wt_small_plane_bytes(T, F);
-    if (pl > a) a = pl;
-    return (long long)a + ((long long)T * wt_small_pitch(T, F) + 64) * 4 + 64;
+    return (long long)wt_small_plane_bytes(T, F) + ((long long)T * wt_small_pitch(T, F) + 64) * 4 + 64;
 }
 __host__ __device__ inline bool wt_small_unit(int T, int F) {
     return T >= 1 && T <= WT_SMALL_MAX_T && F >= 1 && F <= WT_MAX_FRAMES && wt_small_lds_bytes(T, F) <= WT_SMALL_MAX_LDS;

@@ -1,32 +1,32 @@
-// Fused alignment of SMALL units: local cost + DTW + backtrack in ONE workgroup, the cost matrix never leaves LDS.
+// Fused tail of the alignment of SMALL units: column norm + cost[0,0] + DTW + backtrack in ONE workgroup, the cost matrix
+// in LDS.
 //
 // The reference's default call shape (transcribe.py:544-557, trust_whisper_timestamps=True) aligns segment by
 // segment: one perform_word_alignment (transcribe.py:1428-1793) per Whisper segment, T p50 11 tokens x F p50 144
-// frames.  For such units the batched kernels (wt_cost.hip + wt_dtw.hip: rowmean, colnorm, fix00, dtw = up to nine
-// launches, the (T,F) matrix written to and read back from HBM twice) are launch- and latency-bound: 0.045 + 0.061 ms
-// for 160 real-shape units at 0.04 / 0.004 of the HBM peak (profiles/r2q_bench_kreal.json).  Here one workgroup of four
-// waves owns a unit:
-//   1. cost rows   wave w takes token rows w, w+4, ...: head_sum_row (wt_cost_core.h: LDS-DMA of each selected head's
-//                  row, median-9, softmax, head sum in registers) -> the head mean goes to the unit's LDS matrix
+// frames.  For such units the batched kernels (rowmean, colnorm, fix00, dtw: up to nine launches, the (T,F) matrix
+// written, read-modified-written twice and read again) are launch- and latency-bound: 0.045 + 0.061 ms for 160
+// real-shape units at 0.04 / 0.004 of the HBM peak (profiles/r2q_bench_kreal.json).  Here the rows still come from the
+// batched rowmean_kernel (thousands of waves in flight hide the HBM latency of the A*T row fetches; one workgroup
+// fetching its unit's rows itself was measured 4x slower: a wave has one or two rows in flight) and ONE workgroup of
+// four waves does everything after it:
+//   1. load        the unit's head-mean matrix (T*F fp32, what rowmean wrote) HBM -> LDS, every load in flight at once
 //   2. columns     one thread per frame: sum of squares over tokens in f64 with colnorm_kernel's summation tree (the
 //                  matrix is BIT-IDENTICAL to the batched kernels'), normalise, negate, pad mask, unit max
-//   3. cost[0,0] = min; optionally the matrix is written to HBM (callers that keep it: disfluency detection, tests)
+//   3. cost[0,0] = min; optionally the matrix goes back to HBM (callers that keep it: disfluency detection, tests)
 //   4. DTW         wave 0, one lane per token row, the anti-diagonal sweep of wt_dtw_core.h reading 32-frame blocks of
 //                  its row from LDS (the matrix is stored SKEWED, row i shifted right by i, so that at step s every
 //                  lane reads column s of its row: 16-byte aligned ds_read_b128), direction planes to LDS
 //   5. backtrack   wt_dtw_core.h, planes from LDS -> jumps[T+1] (+ path, distance)
-// HBM traffic of a unit = its A*T*F logits in, 4(T+1) bytes out.  A unit qualifies by its own shape alone
-// (wt_small_unit: T <= 64 and the LDS it needs), so the same unit takes the same path in any batch.
+// The matrix crosses HBM once in each direction instead of five times, and a batch of small units is TWO launches
+// (rowmean + this) instead of up to nine.  A unit qualifies by its own shape alone (wt_small_unit: T <= 64 and the LDS
+// it needs), so the same unit takes the same path in any batch.
 #include <algorithm>
 #include <mutex>
 
-#include "wt_cost_core.h"
 #include "wt_dtw_core.h"
 #include "wt_small.h"
 
 namespace wt {
-
-typedef float float4v_s __attribute__((ext_vector_type(4)));
 
 // 32 consecutive cost values of this lane's (skewed) row, columns [s0, s0 + 32): eight 16-byte LDS reads
 __device__ __forceinline__ void load_blk_lds(const float *rowp, int s0, float (&dst)[BLK]) {
@@ -38,46 +38,45 @@ __device__ __forceinline__ void load_blk_lds(const float *rowp, int s0, float (&
     }
 }
 
-template <int C, typename QT>
-__global__ __launch_bounds__(256) void small_align_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
-                                                          const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                          float *cost_out, int32_t *__restrict__ jumps,
-                                                          int32_t *__restrict__ path_i, int32_t *__restrict__ path_j,
-                                                          int32_t *__restrict__ path_len, double *__restrict__ dist, int unit0,
-                                                          int f_lo, int f_hi, int need_lo, int need_hi) {
+__global__ __launch_bounds__(256) void small_tail_kernel(const wt_seg_desc *__restrict__ segs, float *cost, int write_cost,
+                                                         int32_t *__restrict__ jumps, int32_t *__restrict__ path_i,
+                                                         int32_t *__restrict__ path_j, int32_t *__restrict__ path_len,
+                                                         double *__restrict__ dist, int unit0, int need_lo, int need_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BUF = RowBuf<C, QT>::BUF;
     const int unit = unit0 + blockIdx.x;
     const wt_seg_desc d = segs[unit];
     const int T = d.T, F = d.F;
-    // block-uniform: the unit belongs to the batched kernels, to another F class or to the other LDS class of this one
-    if (!wt_small_unit(T, F) || F <= f_lo || F > f_hi) return;
+    if (!wt_small_unit(T, F)) return;   // block-uniform: the unit belongs to the batched kernels
     const int need = (int)wt_small_lds_bytes(T, F);
-    if (need <= need_lo || need > need_hi) return;
+    if (need <= need_lo || need > need_hi) return;   // ... or to the other launch of this kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = wt_small_pitch(T, F);
-    const int stage_bytes = max(wt_small_stage_bytes(F), wt_small_plane_bytes(T, F));
-    // [ row staging (cost phase) | direction planes (DTW phase) ] [ cost matrix, skewed, + 64 floats of slack ] [ reductions ]
-    float (*stage)[2][BUF] = reinterpret_cast<float (*)[2][BUF]>(smem);
+    // [ direction planes ] [ cost matrix, skewed, + 64 floats of slack ] [ reductions ]
     uint2 *planes = reinterpret_cast<uint2 *>(smem);
-    float *cm = reinterpret_cast<float *>(smem + stage_bytes);
+    float *cm = reinterpret_cast<float *>(smem + wt_small_plane_bytes(T, F));
     float *red = cm + (size_t)T * pitch + 64;
+    float *unit_cost = cost + d.cost_offset;
 
-    for (int e = tid; e < T * pitch + 64; e += 256) cm[e] = 0.f;   // (cells outside a row's frames must be finite)
+    // ---- 1. the head-mean matrix -> cm[t][t + f].  Cells outside a row's frames must be finite: everything is zeroed
+    //         first; then the T*F values are fetched in batches of eight independent, coalesced loads per thread ----
+    for (int e = tid; e < T * pitch + 64; e += 256) cm[e] = 0.f;
     __syncthreads();
-
-    // ---- 1. head mean of every token row -> cm[t][t + f] ----
-    for (int t = wave; t < T; t += 4) {
-        const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
-        f2 acc[C / 2];
-        head_sum_row<C, QT>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, stage[wave], lane, acc);
-        float *dst = cm + (size_t)t * pitch + t + lane * C;
+    const int n_el = T * F;
+    for (int e0 = tid; e0 < n_el; e0 += 256 * 8) {
+        float v[8];
 #pragma unroll
-        for (int q = 0; q < C / 2; ++q) {
-            const int f = lane * C + 2 * q;
-            if (f < F) dst[2 * q] = head_mean(acc[q].x, n_heads);
-            if (f + 1 < F) dst[2 * q + 1] = head_mean(acc[q].y, n_heads);
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + 256 * k;
+            v[k] = e < n_el ? unit_cost[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + 256 * k;
+            if (e < n_el) {
+                const int t = (int)((unsigned)e / (unsigned)F);
+                cm[(size_t)t * (pitch + 1) + (e - t * F)] = v[k];
+            }
         }
     }
     __syncthreads();
@@ -119,12 +118,10 @@ __global__ __launch_bounds__(256) void small_align_kernel(const QT *__restrict__
     // ---- 3. cost[0,0] = min(cost) (transcribe.py:1568); the matrix to HBM for callers that keep it ----
     if (tid == 0) cm[0] = -fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    if (cost_out) {
-        float *out = cost_out + d.cost_offset;
-        for (int t = 0; t < T; ++t)
-            for (int f = tid; f < F; f += 256) out[(size_t)t * F + f] = cm[(size_t)t * pitch + t + f];
-    }
-    if (wave != 0) return;   // (no barrier below: the staging area is free for the planes since the barrier above)
+    if (write_cost)
+        for (int t = wave; t < T; t += 4)
+            for (int f = lane; f < F; f += 64) unit_cost[(size_t)t * F + f] = cm[(size_t)t * pitch + t + f];
+    if (wave != 0) return;   // (no barrier below)
 
     // ---- 4. DTW sweep on wave 0: lane = token row ----
     const int i = lane;
@@ -165,12 +162,10 @@ __global__ __launch_bounds__(256) void small_align_kernel(const QT *__restrict__
                    path_len);
 }
 
-template <int C, typename QT>
-static int launch_small(const QT *qk, const wt_seg_desc *segs_dev, int unit0, int n, int f_lo, int f_hi, int need_lo,
-                        int need_hi, const int32_t *head_idx, int n_heads, float qk_scale, float *cost, int32_t *jumps,
-                        int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+static int launch_tail(const wt_seg_desc *segs_dev, int unit0, int n, int need_lo, int need_hi, float *cost, int write_cost,
+                       int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
     static std::mutex mu;
-    static bool attr_set[64] = {false};   // function attributes are per (instantiation, device)
+    static bool attr_set[64] = {false};   // function attributes are per device
     int dev = 0;
     WT_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) {
@@ -180,71 +175,41 @@ static int launch_small(const QT *qk, const wt_seg_desc *segs_dev, int unit0, in
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!attr_set[dev]) {
-            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_align_kernel<C, QT>),
+            WT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(small_tail_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL((small_align_kernel<C, QT>), dim3(n), dim3(256), (size_t)need_hi, st, qk, segs_dev, head_idx, n_heads,
-                       qk_scale, cost, jumps, path_i, path_j, path_len, dist, unit0, f_lo, f_hi, need_lo, need_hi);
+    hipLaunchKernelGGL(small_tail_kernel, dim3(n), dim3(256), (size_t)need_hi, st, segs_dev, cost, write_cost, jumps, path_i, path_j,
+                       path_len, dist, unit0, need_lo, need_hi);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }
 
-// Launch plan: units are grouped by the row instantiation their F needs (C = 4, 8, 16 or 28 elements per lane) and,
-// inside a group, by LDS appetite ("light" <= WT_SMALL_LIGHT_LDS: several workgroups per CU; "heavy": the rest), each
-// (group, appetite) present = one launch over the group's unit range with the largest LDS of its members.
-template <typename QT>
-static int align_small_t(const QT *qk, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
-                         const int32_t *head_idx, int n_heads, float qk_scale, float *cost, int32_t *jumps, int32_t *path_i,
-                         int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
-    static const int f_edges[5] = {0, 256, 512, 1024, WT_MAX_FRAMES};
-    for (int c = 0; c < 4; ++c) {
-        int lo = -1, hi = -1, light_max = 0, heavy_max = 0;
-        for (int s = 0; s < n_seg; ++s) {
-            const wt_seg_desc &d = segs_host[s];
-            if (!wt_small_unit(d.T, d.F) || d.F <= f_edges[c] || d.F > f_edges[c + 1]) continue;
-            if (lo < 0) lo = s;
-            hi = s;
-            const int need = (int)wt_small_lds_bytes(d.T, d.F);
-            if (need <= WT_SMALL_LIGHT_LDS) light_max = std::max(light_max, need);
-            else heavy_max = std::max(heavy_max, need);
-        }
-        if (lo < 0) continue;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int need_lo = pass == 0 ? 0 : WT_SMALL_LIGHT_LDS, need_hi = pass == 0 ? light_max : heavy_max;
-            if (need_hi == 0) continue;
-            int rc;
-#define WT_SMALL_CASE(CI, CC)                                                                                              \
-    case CI:                                                                                                               \
-        rc = launch_small<CC, QT>(qk, segs_dev, lo, hi - lo + 1, f_edges[c], f_edges[c + 1], need_lo, need_hi, head_idx,    \
-                                  n_heads, qk_scale, cost, jumps, path_i, path_j, path_len, dist, st);                     \
-        break;
-            switch (c) {
-                WT_SMALL_CASE(0, 4)
-                WT_SMALL_CASE(1, 8)
-                WT_SMALL_CASE(2, 16)
-                default:
-                WT_SMALL_CASE(3, 28)
-            }
-#undef WT_SMALL_CASE
-            if (rc) return rc;
-        }
+// ONE launch over the range of the small units, with the largest LDS appetite among them -- a launch lasts as long as
+// its longest DTW chain, so splitting a batch by size would add the chains up.  Only a batch with more small units than
+// the chip has CUs is split in two ("light" units <= WT_SMALL_LIGHT_LDS share a CU four or five at a time).
+int align_small_tail(const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, float *cost, bool keep_cost,
+                     int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
+    int lo = -1, hi = -1, n_small = 0, light_max = 0, heavy_max = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        const wt_seg_desc &d = segs_host[s];
+        if (!wt_small_unit(d.T, d.F)) continue;
+        if (lo < 0) lo = s;
+        hi = s;
+        ++n_small;
+        const int need = (int)wt_small_lds_bytes(d.T, d.F);
+        if (need <= WT_SMALL_LIGHT_LDS) light_max = std::max(light_max, need);
+        else heavy_max = std::max(heavy_max, need);
     }
-    return WT_OK;
-}
-
-int align_small(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
-                const int32_t *head_idx, int n_heads, float qk_scale, float *cost, int32_t *jumps, int32_t *path_i,
-                int32_t *path_j, int32_t *path_len, double *dist, hipStream_t st) {
-    if (qk_dtype == WT_DTYPE_F32)
-        return align_small_t((const float *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, jumps, path_i,
-                             path_j, path_len, dist, st);
-    if (qk_dtype == WT_DTYPE_F16)
-        return align_small_t((const __half *)qk, segs_host, segs_dev, n_seg, head_idx, n_heads, qk_scale, cost, jumps, path_i,
-                             path_j, path_len, dist, st);
-    set_error("wt_align_batch: qk_dtype=%d", qk_dtype);
-    return WT_E_BADARG;
+    if (lo < 0) return WT_OK;
+    const int wc = keep_cost ? 1 : 0;
+    if (n_small <= 256 || light_max == 0 || heavy_max == 0)
+        return launch_tail(segs_dev, lo, hi - lo + 1, 0, std::max(light_max, heavy_max), cost, wc, jumps, path_i, path_j, path_len,
+                           dist, st);
+    int rc = launch_tail(segs_dev, lo, hi - lo + 1, 0, light_max, cost, wc, jumps, path_i, path_j, path_len, dist, st);
+    if (rc) return rc;
+    return launch_tail(segs_dev, lo, hi - lo + 1, WT_SMALL_LIGHT_LDS, heavy_max, cost, wc, jumps, path_i, path_j, path_len, dist, st);
 }
 
 }  // namespace wt
