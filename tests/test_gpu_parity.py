@@ -741,3 +741,31 @@ def test_disfluency_kernel_vs_scipy():
         moved += int((want != j).sum())
     assert moved > 20
     assert L.wt_disfluency_batch(0, dd.data_ptr(), 1, jp.data_ptr(), out.ctypes.data, 0.02, 3.0, 0) == -1     # WT_E_BADARG
+
+
+def test_per_device_state_second_device_first():
+    """The library keeps per-DEVICE state (the log-mel __constant__ tables, the scratch arenas, the DTW kernels' dynamic-LDS
+    attribute): a process that touches cuda:1 BEFORE cuda:0 must get the same results on both (round 2 uploaded the
+    tables once per process: the second device computed log-mel from zeros).  Needs two visible GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the per-device paths cannot be exercised on this box")
+    L = _lib()
+    from whisper_timestamped.audio import mel_filters
+    g = torch.Generator().manual_seed(3)
+    pcm = torch.randn((2, 48000), generator=g) * 0.1
+    want = torch.stack([O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b], 80), 3000) for b in range(2)])
+    costs = [np.random.RandomState(5).standard_normal((70, 300)).astype(np.float32) - 3.0]
+    ref = O.dtw_ref(costs[0].astype(np.float64))
+    for dev in ("cuda:1", "cuda:0"):
+        mel, _ = L.logmel(pcm.to(dev), mel_filters(dev, 80), None, 3000)
+        assert (mel.cpu() - want).abs().max() < 2e-4, dev
+        with torch.cuda.device(dev):
+            descs = L.make_descs(1)
+            descs[0]["T"], descs[0]["F"], descs[0]["pad_from"] = 70, 300, -1
+            n_cost, n_jumps, _ = L.layout_outputs(descs)
+            flat = np.zeros(n_cost, dtype=np.float32)
+            flat[:70 * 300] = costs[0].ravel()
+            jumps = torch.zeros(n_jumps, dtype=torch.int32, device=dev)
+            L.dtw_batch(torch.from_numpy(flat).to(dev), descs, L.descs_to_device(descs, dev), jumps)
+            torch.cuda.synchronize(dev)
+        assert np.array_equal(jumps.cpu().numpy(), O.jumps_from_path(ref.index1s, ref.index2s)), dev

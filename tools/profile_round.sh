@@ -13,7 +13,7 @@ out=$ROOT/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --workload $wl"
-K="$B --e2e off --no-cpu-baseline --pipeline 1"   # kernel trace / PMC passes: one batch in flight, stages back to back (what the stage times and the roofline are measured on)
+K="$B --role kernel --pipeline 1"   # kernel trace / PMC passes: the kernel-level leg itself (bench.py's child process), one batch in flight, stages back to back (what the stage times and the roofline are measured on)
 timeout 600 $B --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- $K --steps 10 --warmup 2 --repeats 5 > "$out/kt.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$out/pmc_fetch" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_fetch.log" 2>&1
@@ -23,7 +23,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VM
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d "$out/pmc_sq2" -o pmc -- $K --steps 3 --warmup 1 --repeats 1 > "$out/pmc_sq2.log" 2>&1
 python $ROOT/tools/pmc_counters.py $(find "$out/pmc_sq1" "$out/pmc_sq2" -name "*.db") > "$out/sq_counters.txt" 2> "$out/sq_counters.err"
 if [ "$wl" = kfull ]; then
-  timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt_e2e" -o kt -- $B --e2e on --no-cpu-baseline --steps 1 --warmup 1 --repeats 1 --e2e-steps 3 > "$out/kt_e2e.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$out/kt_e2e" -o kt -- $B --role e2e --leg fp32 --no-cpu-baseline --e2e-steps 3 > "$out/kt_e2e.log" 2>&1
   ke=$(find "$out/kt_e2e" -name "*.db" | head -1)
   python $ROOT/tools/rocpd_stats.py "$ke" > "$out/e2e_kernel_stats.txt" 2>&1
 fi
