@@ -113,7 +113,7 @@ def case_odd_units(mode, dtype, flags=1):
     dev = "cuda:0"
     shapes = [(1, 0, 1), (2, 0, 3), (3, 10, 14), (5, 1, 8), (9, 100, 245), (17, 275, 523), (11, 3, 258), (64, 0, 1500),
               (65, 219, 1500), (31, 1, 770), (130, 0, 1281), (224, 0, 1500), (255, 7, 1499), (64, 3, 258), (16, 0, 1500),
-              (30, 100, 1125), (7, 1, 513)]
+              (30, 100, 1125), (7, 1, 513), (74, 100, 400), (130, 0, 60), (150, 2, 32)]
     heads = list(range(6))
     qk_list = [synth.synth_qk(300 + k, 6, T, lo=s, hi=e) for k, (T, s, e) in enumerate(shapes)]
     order = L.launch_order([(T, e - s) for T, s, e in shapes])

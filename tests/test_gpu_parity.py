@@ -365,15 +365,17 @@ def _align_units(shapes, dtype, flags, seed=0, n_heads=8, want_path=True):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_fused_small_units_equal_the_batched_kernels(dtype):
-    """wt_align_batch_v3: units of the reference's per-segment shape (T <= 64, matrix in LDS) take ONE fused kernel
-    (wt_small.hip); cost, jumps, path and distance must be BIT-identical to the batched kernels' (rowmean / colnorm /
-    fix00 / dtw) on the same units -- every F class, tiny units, odd F, pad masks, the largest qualifying shapes -- and
-    the jumps bit-exact against the oracle DTW fed with that cost."""
+    """wt_align_batch_v3: units whose (T, F) matrix fits a workgroup's LDS (the reference's per-segment shape) leave the
+    batched kernels after the row pass: ONE fused kernel (wt_small.hip) does column norm, cost[0,0], DTW and backtrack.
+    cost, jumps, path and distance must be BIT-identical to the batched kernels' (colnorm / fix00 / dtw) on the same
+    units -- every F class, tiny units, odd F, pad masks, one to four sweeping waves, the largest qualifying shapes --
+    and the jumps bit-exact against the oracle DTW fed with that cost."""
     L = _lib()
     rng = np.random.RandomState(31)
     shapes = [(1, 0, 1), (1, 5, 9), (2, 0, 3), (3, 10, 14), (5, 1, 8), (9, 100, 245), (11, 3, 147), (17, 275, 523), (11, 3, 258),
               (64, 0, 256), (64, 1000, 1447), (63, 7, 300), (31, 1, 770), (30, 0, 1025), (16, 0, 1500), (4, 200, 1197), (8, 0, 1792 - 300),
-              (33, 2, 900), (65, 0, 200), (224, 0, 1500), (12, 0, 64), (2, 1400, 1500)]
+              (33, 2, 900), (65, 0, 200), (224, 0, 1500), (12, 0, 64), (2, 1400, 1500), (74, 100, 400), (128, 0, 190), (129, 5, 160),
+              (200, 0, 100), (256, 0, 60), (192, 3, 130), (100, 0, 260), (70, 1, 2), (130, 0, 1), (130, 0, 60), (150, 2, 32), (191, 0, 9)]
     Ts, Fs = synth.draw_real_shapes(77, 60)
     for T, F in zip(Ts, Fs):
         s = int(rng.randint(0, 1500 - int(F) + 1))
@@ -393,12 +395,12 @@ def test_fused_small_units_equal_the_batched_kernels(dtype):
         assert float(fused["dist"][k]) == float(plain["dist"][k]), (T, F)
         r = O.dtw_ref(a.reshape(T, F).cpu().numpy().astype(np.float64))
         assert np.array_equal(fused["jumps"][j0:j0 + T + 1].cpu().numpy(), O.jumps_from_path(r.index1s, r.index2s)), (T, F)
-        n_small += int(T <= 64)
-    assert n_small > 60
+        n_small += int(L.small_unit(T, F))
+    assert n_small > 60 and n_small < len(shapes)
     # without WT_ALIGN_KEEP_COST the fused units leave no matrix behind, the others do; jumps are the same
     lean = _align_units(shapes, dtype, 0, want_path=False)
     assert torch.equal(lean["jumps"], plain["jumps"])
-    kept = [int(d["T"]) > 64 for d in lean["descs"]]
+    kept = [not L.small_unit(int(d["T"]), int(d["F"])) for d in lean["descs"]]
     for d, k in zip(lean["descs"], kept):
         c0, n = int(d["cost_offset"]), int(d["T"]) * int(d["F"])
         if k:

@@ -78,9 +78,6 @@ __device__ __forceinline__ void load_blk_tiny(const float *__restrict__ unit, in
     }
 }
 
-__host__ __device__ inline int dtw_blocks(int F) { return (F + 63 + BLK - 1) / BLK; }        // 32-step blocks of a sweep
-__host__ __device__ inline int dtw_bnd_pitch(int F) { return (F + 64 + BLK + 1) & ~1; }      // doubles per boundary row (even: 16-byte rows)
-constexpr int DUMP = 64 + BLK;  // doubles per producer wave: where lanes 0..62 park the per-step store only lane 63 needs
 
 // The two plane words of a finished block -> the unit's scratch slot: ONE 8-byte buffer store per lane on a descriptor
 // of the slot (base = the unit's first plane word, range = its slot): the compiler sees the store (it keeps its own

@@ -9,6 +9,9 @@
 namespace wt {
 
 constexpr int BLK = 32;  // steps per block = bits per direction word
+__host__ __device__ inline int dtw_blocks(int F) { return (F + 63 + BLK - 1) / BLK; }        // 32-step blocks of a sweep
+__host__ __device__ inline int dtw_bnd_pitch(int F) { return (F + 64 + BLK + 1) & ~1; }      // doubles per boundary row (even: 16-byte rows)
+constexpr int DUMP = 64 + BLK;  // doubles per producer wave: where lanes 0..62 park the per-step store only lane 63 needs
 
 // in-place wave_shr:1 -- lane 0 keeps what `up` already holds (its +inf)
 __device__ __forceinline__ void shift_in(double &up, double g) {

@@ -216,6 +216,21 @@ def descs_to_device(descs: np.ndarray, device) -> torch.Tensor:
     return raw.to(device, non_blocking=False)
 
 
+def small_unit(T: int, F: int) -> bool:
+    """Mirror of wt_small_unit (csrc/wt_small.h): does a unit of T tokens x F frames take the fused tail kernel of
+    wt_align_batch_v3 (column norm, cost[0,0], DTW and backtrack in one workgroup, the matrix in LDS)?  Informational
+    (tests, diagnostics): the library decides by itself."""
+    if not (1 <= T <= WT_MAX_TOKENS and 1 <= F <= WT_MAX_FRAMES):
+        return False
+    nw = (T + 63) // 64
+    pitch = (F + T + 3) & ~3
+    if pitch & 4 == 0:
+        pitch += 4
+    planes = ((F + 63 + 31) // 32 + 1) * 64 * nw * 8
+    bnd = (nw - 1) * (((F + 64 + 32 + 1) & ~1) + 96) * 8 + 16
+    return planes + bnd + (T * pitch + 192) * 4 + 64 <= 160 * 1024
+
+
 def launch_order(shapes):
     """Order in which to hand units to the library: grouped by the cost kernel's F class (ceil(F/256)), longest
     first inside a class.  wt_cost_batch then launches every class over its own units only (wt_cost.hip)."""
