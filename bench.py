@@ -611,7 +611,9 @@ def parse_args(argv=None):
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
     # --- process plumbing (see orchestrate()): the measuring legs run in child processes of this script
     ap.add_argument("--role", default="orchestrate", choices=["orchestrate", "kernel", "cpu", "e2e"], help=argparse.SUPPRESS)
-    ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16"], help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient"], help=argparse.SUPPRESS)
+    ap.add_argument("--e2e-workers", type=int, default=2,
+                    help="worker processes per GPU of the default-strategy leg (sharding.transcribe_many)")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (gloo on the CPU, no kernels, meaningless numbers): what "
@@ -907,13 +909,41 @@ def role_cpu(args):
     emit(out)
 
 
+def run_efficient_leg(args, emit):
+    """The DEFAULT strategy of transcribe() (the reference's efficient strategy: word alignment on the fly while the
+    backend decodes, T.py:359-1001), 30 s synthetic clips with a scripted ~110-token transcript in 5 segments on the whisper
+    double: one process (what a caller of the reference's API gets: the backend's Python loop, one stream, one token at
+    a time) and `--e2e-workers` worker processes sharing the GPU (sharding.transcribe_many: recordings are independent
+    units).  Timed between a common start after every worker's warm-up clip and the slowest worker's last result."""
+    import many_helper as H          # tests/: the whisper double as the model, the scripted transcript
+    from whisper_timestamped.sharding import transcribe_many
+    g = torch.Generator().manual_seed(7)
+    clip = (0.05 * torch.randn(30 * 16000, generator=g)).float()
+    out = {"workload": "whisper-base (random init, fp32), 30 s synthetic clips, scripted transcript of ~110 tokens in 5 "
+                       "timestamped segments, transcribe() with its defaults (efficient strategy, greedy)"}
+    for workers, per_worker in ((1, 4), (args.e2e_workers, 4)):
+        n = workers * per_worker
+        res, seconds = transcribe_many(H.load_base, [clip] * n, workers_per_gpu=workers, devices=["cuda:0"], on_item=H.script_clip,
+                                       warmup=True, return_timing=True, language="en", fp16=False)
+        n_words = sum(len(s["words"]) for r in res for s in r["segments"])
+        assert n_words > 0
+        out[f"{workers}_process{'es' if workers > 1 else ''}"] = {
+            "audio_s_per_s": round(30.0 * n / seconds, 1), "clips": n, "seconds": round(seconds, 3),
+            "ms_per_clip_per_process": round(1e3 * seconds / per_worker, 1), "words": n_words}
+        emit(out)
+    return out
+
+
 def role_e2e(args):
     emit = make_emitter(args.out)
     if args.inject_fault == "e2e_" + args.leg:
         emit({"marker": "about to abort"})
         os.abort()
     torch.cuda.set_device(0)
-    run_e2e(torch.device("cuda", 0), args, args.leg, emit)
+    if args.leg == "efficient":
+        run_efficient_leg(args, emit)
+    else:
+        run_e2e(torch.device("cuda", 0), args, args.leg, emit)
 
 
 def run_child(role, extra, timeout_s, env=None):
@@ -1011,6 +1041,12 @@ def orchestrate(args):
             e2e.update(half)
             if e2:
                 e2e["fp16_legs_error"] = e2
+            eff, e3 = run_child("e2e", ["--leg", "efficient"], 600)
+            eff = eff or {}
+            eff.pop("marker", None)
+            if e3:
+                eff["error"] = e3
+            e2e["default_strategy"] = eff
             out["e2e"] = e2e
     print(json.dumps(out), flush=True)
     if out.get("value") is None:

@@ -1,0 +1,32 @@
+"""Picklable helpers for sharding.transcribe_many's worker processes (test / bench infrastructure): the whisper double
+as the model, and a scripted ~110-token transcript per 30 s clip (the same script tools/bench_transcribe.py times)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def load_base(device):
+    import whisper_double as W
+    W.install()
+    return W.build_model("base", seed=0, device=device)
+
+
+def load_tiny(device):
+    import whisper_double as W
+    W.install()
+    return W.build_model("tiny", seed=0, device=device)
+
+
+SEGMENTS = [(0, 20, 280), (300, 22, 600), (620, 18, 900), (920, 21, 1200), (1220, 19, 1490)]   # (start frame, text tokens, end frame)
+
+
+def script_clip(index):
+    """Before item `index`: the decoder of the double follows a scripted transcript (5 timestamped segments, ~110 tokens)."""
+    from whisper_double.decoding import Script, set_script
+    from golden import make_golden_transcribe as G
+    segs = [(s, [None] * n, e) for s, n, e in SEGMENTS]
+    set_script(Script([G.window_script(50364, 50257, segs, "eot")]))

@@ -322,3 +322,30 @@ def test_islands_job_matches_reference_per_island():
     assert seen == [0, 1, 2, 3]
     dt, dc = _check_islands_result(result, job, time_tol=0.02, conf_tol=1e-3 + 1e-4)
     _report("islands_job", dt, dc)
+
+
+def test_transcribe_many_worker_processes_equal_serial():
+    """sharding.transcribe_many: recordings dealt to several worker processes on ONE GPU (the default strategy decodes one
+    stream per process and is host-bound: independent recordings are the unit of parallelism) -- the dictionaries must be
+    those of transcribe() called serially in this process."""
+    import many_helper as H
+    import whisper_timestamped as wt
+    from whisper_double.decoding import set_script
+    from whisper_timestamped.sharding import transcribe_many
+    g = torch.Generator().manual_seed(11)
+    audios = [(0.05 * torch.randn(n, generator=g)).float() for n in (30 * 16000, 12 * 16000, 30 * 16000, 7 * 16000, 21 * 16000)]
+    model = H.load_base("cuda:0")
+    serial = []
+    for k, a in enumerate(audios):
+        H.script_clip(k)
+        serial.append(wt.transcribe(model, a, language="en", fp16=False))
+    set_script(None)
+    many, seconds = transcribe_many(H.load_base, audios, workers_per_gpu=3, devices=["cuda:0"], on_item=H.script_clip,
+                                    return_timing=True, language="en", fp16=False)
+    assert seconds > 0 and len(many) == len(serial)
+    for a, b in zip(many, serial):
+        assert a["text"] == b["text"] and len(a["segments"]) == len(b["segments"])
+        for sa, sb in zip(a["segments"], b["segments"]):
+            assert [w["text"] for w in sa["words"]] == [w["text"] for w in sb["words"]]
+            for wa, wb in zip(sa["words"], sb["words"]):
+                assert wa["start"] == wb["start"] and wa["end"] == wb["end"] and wa["confidence"] == wb["confidence"]

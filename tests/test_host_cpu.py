@@ -254,3 +254,30 @@ def test_output_surface_matches_reference():
         assert got == exp, name
     assert list(output.flatten([[1, 2], [3]])) == [1, 2, 3]
     assert list(output.flatten([{"a": [1]}, {}], "a")) == [1]
+
+
+def test_small_unit_mirror_matches_the_header(tmp_path):
+    """_lib.small_unit (Python, informational) against wt_small_unit (csrc/wt_small.h, what the library and its kernels
+    decide with): the header is compiled into a host program that prints the decision for a grid of shapes."""
+    import shutil
+    import subprocess
+    from whisper_timestamped import _lib
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    src = tmp_path / "probe.hip"
+    src.write_text('#include <cstdio>\n#include "wt_small.h"\n'
+                   'int main() { for (int T = 1; T <= 256; ++T) for (int F = 1; F <= 1792; F += (F < 40 ? 1 : 37))\n'
+                   '  std::printf("%d %d %d %lld\\n", T, F, (int)wt::wt_small_unit(T, F), wt::wt_small_lds_bytes(T, F)); return 0; }\n')
+    exe = tmp_path / "probe"
+    csrc = os.path.join(ROOT, "whisper-timestamped_amd", "csrc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-std=c++17", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])      # (host program: nothing is launched, no GPU needed)
+    n = small = 0
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        T, F, want, need = map(int, line.split())
+        assert _lib.small_unit(T, F) == bool(want), (T, F, need)
+        n += 1
+        small += want
+    assert n > 20000 and 0 < small < n
+    assert _lib.small_unit(11, 144) and _lib.small_unit(64, 256) and not _lib.small_unit(224, 1500)

@@ -201,3 +201,80 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
     by_index = dict(mine)
     assert sorted(by_index) == list(range(len(islands)))
     return merge_island_results([by_index[i] for i in range(len(islands))], islands)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Many recordings, several worker processes per GPU
+# ----------------------------------------------------------------------------------------------------------------------
+# The default (efficient) strategy decodes ONE stream token by token inside the ASR backend's own Python loop
+# (transcribe.py:806 asserts batch 1): 2.7 ms of host time per token against a few hundred microseconds of GPU time, so one
+# process leaves the GPU idle nine tenths of the time.  Recordings are independent units: W worker processes per GPU, each
+# with its own copy of the model (whisper-base: 290 MB of 288 GB) and its own HIP queues, fill the GPU the way W batch
+# streams would, with no change to the backend's loop and therefore to its output.  No collective anywhere: a job queue
+# in, result dictionaries out.
+def _many_worker(rank, n_workers, devices, load_model, audios, order, options, barrier, out_queue, on_item, warmup):
+    import time
+    dev = devices[rank % len(devices)]
+    torch.cuda.set_device(dev)
+    from .transcribe import transcribe_timestamped
+    model = load_model(dev)
+    mine = order[rank]
+    if warmup and mine:                          # allocations, GEMM plans, the library's arenas: before the common start
+        if on_item is not None:
+            on_item(mine[0])
+        transcribe_timestamped(model, audios[mine[0]], **options)
+    torch.cuda.synchronize(dev)
+    if barrier is not None:
+        barrier.wait()
+    t0 = time.perf_counter()
+    res = []
+    for i in mine:
+        if on_item is not None:
+            on_item(i)
+        res.append((i, transcribe_timestamped(model, audios[i], **options)))
+    torch.cuda.synchronize(dev)
+    out_queue.put((rank, time.perf_counter() - t0, res))
+
+
+def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, on_item=None, warmup: bool = False,
+                    return_timing: bool = False, **options):
+    """transcribe_timestamped() of every recording in `audios` (1-D fp32 tensors / arrays at 16 kHz, or paths) on
+    `workers_per_gpu` worker processes per GPU.  `load_model(device)` -> the model; it runs inside each worker and must
+    be picklable (a module-level function), as must `on_item(index)` (called in the worker before item `index`).
+    Recordings are dealt to the workers largest-first by length.  Returns the result dictionaries in the order of
+    `audios` (with `return_timing`: also the slowest worker's seconds between the common start and its last result)."""
+    import torch.multiprocessing as mp
+    from .naive import get_audio_tensor
+    devices = list(devices) if devices is not None else [f"cuda:{k}" for k in range(torch.cuda.device_count())]
+    assert devices, "transcribe_many needs at least one GPU"
+    audios = [get_audio_tensor(a).cpu() for a in audios]
+    n_workers = max(1, min(workers_per_gpu * len(devices), len(audios)))
+    order = partition_units([int(a.numel()) for a in audios], n_workers)
+    ctx = mp.get_context("spawn")
+    barrier = ctx.Barrier(n_workers)
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, audios, order, options, barrier, queue,
+                                                    on_item, warmup)) for r in range(n_workers)]
+    for p in procs:
+        p.start()
+    got, slowest = {}, 0.0
+    try:
+        for _ in procs:
+            while True:
+                try:
+                    rank, seconds, res = queue.get(timeout=5.0)
+                    break
+                except Exception:              # noqa: BLE001  (queue.Empty: is everybody still alive?)
+                    dead = [p for p in procs if p.exitcode not in (None, 0)]
+                    if dead:
+                        raise RuntimeError(f"transcribe_many: a worker died (exit code {dead[0].exitcode})")
+            slowest = max(slowest, seconds)
+            got.update(dict(res))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    assert sorted(got) == list(range(len(audios)))
+    results = [got[i] for i in range(len(audios))]
+    return (results, slowest) if return_timing else results
