@@ -771,3 +771,58 @@ def test_per_device_state_second_device_first():
             L.dtw_batch(torch.from_numpy(flat).to(dev), descs, L.descs_to_device(descs, dev), jumps)
             torch.cuda.synchronize(dev)
         assert np.array_equal(jumps.cpu().numpy(), O.jumps_from_path(ref.index1s, ref.index2s)), dev
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_cost_and_jumps_do_not_depend_on_the_batch(dtype):
+    """A unit's cost matrix and jumps are a function of the unit alone: the same unit aligned alone, in a batch of its own
+    F class, and in a batch that holds every F class (short units then share a launch with the (256, 512] class) gives
+    bit-identical results.  (Round 2 served short units with the 8-elements-per-lane rowmean whenever the batch also held
+    a (256, 512] unit: last-place differences in the softmax denominator.)"""
+    L = _lib()
+    probe = [(11, 3, 147), (64, 0, 256), (9, 100, 245), (30, 40, 392), (17, 275, 523), (70, 100, 400), (12, 0, 700), (6, 0, 1100)]
+    others = [(20, 0, 300), (33, 10, 500), (40, 0, 600), (12, 0, 900), (9, 0, 1300), (100, 0, 1500), (5, 1, 8), (64, 200, 456)]
+    alone = []
+    for k, sh in enumerate(probe):
+        r = _align_units([sh], dtype, L.WT_ALIGN_KEEP_COST, seed=500 + k, want_path=False)
+        d = r["descs"][0]
+        T, F = int(d["T"]), int(d["F"])
+        alone.append((r["cost"][:T * F].clone(), r["jumps"][:T + 1].clone()))
+
+    def in_batch(shapes, seeds):
+        # (_align_units seeds unit k with seed + k: build the batch unit by unit so that every probe keeps its own data)
+        qk_list = [synth.synth_qk(sd, 8, T, lo=s, hi=e) for sd, (T, s, e) in zip(seeds, shapes)]
+        order = L.launch_order([(T, e - s) for T, s, e in shapes])
+        descs = L.make_descs(len(shapes))
+        offs, off = [], 0
+        for q in qk_list:
+            offs.append(off)
+            off += q.size
+        for d, i in zip(descs, order):
+            T, s, e = shapes[i]
+            q = qk_list[i]
+            d["qk_offset"], d["head_stride"], d["row_stride"] = offs[i], q.shape[1] * q.shape[2], q.shape[2]
+            d["T"], d["F"], d["start_token"], d["pad_from"] = T, e - s, s, (-1 if i % 3 else max((e - s) // 2, 1))
+        n_cost, n_jumps, _ = L.layout_outputs(descs)
+        qk = torch.from_numpy(np.concatenate([q.ravel() for q in qk_list])).to(DEV).to(dtype)
+        cost = torch.zeros(n_cost, dtype=torch.float32, device=DEV)
+        jumps = torch.zeros(n_jumps, dtype=torch.int32, device=DEV)
+        L.align_batch(qk, descs, L.descs_to_device(descs, DEV), torch.arange(8, dtype=torch.int32, device=DEV), cost, jumps)
+        torch.cuda.synchronize()
+        return {i: (d, cost, jumps) for d, i in zip(descs, order)}
+
+    # unit i of _align_units([sh]) had pad index rule "i % 3" with i = 0 -> a mask: give the probes index 0 mod 3 in the batch
+    shapes, seeds, where = [], [], []
+    for k, sh in enumerate(probe):
+        where.append(len(shapes))
+        shapes.append(sh)
+        seeds.append(500 + k)
+        for j in range(2):                      # two fillers keep the next probe at an index divisible by 3
+            shapes.append(others[(2 * k + j) % len(others)])
+            seeds.append(900 + 2 * k + j)
+    got = in_batch(shapes, seeds)
+    for (c_alone, j_alone), w in zip(alone, where):
+        d, cost, jumps = got[w]
+        T, F, c0, j0 = int(d["T"]), int(d["F"]), int(d["cost_offset"]), int(d["jumps_offset"])
+        assert torch.equal(cost[c0:c0 + T * F], c_alone), f"cost of unit (T={T}, F={F}) depends on the batch"
+        assert torch.equal(jumps[j0:j0 + T + 1], j_alone), (T, F)

@@ -187,24 +187,24 @@ static bool class_ranges(const wt_seg_desc *segs_host, int n_seg, ClassRange (&c
     return grouped;
 }
 
-// Launch plan: at most TWO rowmean (and colnorm) launches per call -- "short" windows (F <= 512) with the 8-elements-
-// per-lane instantiation and everything longer with the instantiation of the longest window present -- because a
-// mixed batch is launch-bound, not work-bound (160 real-shape units: 11 launches 68 us -> 5 launches).  A batch
-// whose units all fall in one class keeps that class's exact instantiation.
+// Launch plan.  Every unit is served by the rowmean instantiation of ITS OWN F class (C = 4 * ceil(F / 256) elements per
+// lane), so that its cost matrix does not depend on what else is in the batch -- with one exception that costs nothing in
+// that respect: classes 0 and 1 (F <= 512, where the reference's per-segment units live) share ONE launch of the
+// 8-elements-per-lane instantiation when both are present, because that instantiation reproduces the 4-element one's
+// rows bit for bit on F <= 256 (wt_cost_core.h: the softmax denominator's summation tree).  A mixed batch is
+// launch-bound, not work-bound: classes 2..6 each get their own launch only when present.
 struct LaunchGroup {
     int ci = -1;            // instantiation index: C = 4 * (ci + 1)
     int lo = 0, n = 0;      // unit range when grouped
     int maxT = 0, maxF = 0, f_lo = 0, f_hi = 0;
 };
-static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2], bool &contiguous) {
-    int first = -1, last = -1, present = 0;
-    for (int c = 0; c < 7; ++c)
-        if (cls[c].any) { if (first < 0) first = c; last = c; ++present; }
+constexpr int MAX_GROUPS = 6;
+static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[MAX_GROUPS], bool &contiguous) {
     auto fill = [&](LaunchGroup &out, int c0, int c1, int ci) {
         out = LaunchGroup();
         out.ci = ci;
         out.f_lo = c0 * 256;
-        out.f_hi = ((c1 < ci ? c1 : ci) + 1) * 256;   // never beyond the instantiation's capacity
+        out.f_hi = (c1 + 1) * 256;
         int lo = 1 << 30, hi = 0, members = 0;
         for (int c = c0; c <= c1; ++c)
             if (cls[c].any) {
@@ -218,11 +218,12 @@ static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[2], bool &co
         out.n = hi - lo;
         if (out.n != members) contiguous = false;     // the group's classes are not adjacent in the unit order
     };
-    if (present == 0) return 0;
-    if (present == 1) { fill(g[0], first, first, first); return 1; }
     int ng = 0;
-    if (first <= 1) { fill(g[ng], 0, 1, cls[1].any ? 1 : 0); ++ng; }
-    if (last >= 2) { fill(g[ng], 2, 6, last); g[ng].f_hi = (last + 1) * 256; ++ng; }
+    if (cls[0].any && cls[1].any) fill(g[ng++], 0, 1, 1);
+    else if (cls[0].any) fill(g[ng++], 0, 0, 0);
+    else if (cls[1].any) fill(g[ng++], 1, 1, 1);
+    for (int c = 2; c < 7; ++c)
+        if (cls[c].any) fill(g[ng++], c, c, c);
     return ng;
 }
 
@@ -288,10 +289,10 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     if (rc) return rc;
     ClassRange cls[7];
     bool grouped = class_ranges(segs_host, n_seg, cls);
-    LaunchGroup groups[2];
+    LaunchGroup groups[MAX_GROUPS];
     const int n_groups = plan_groups(cls, groups, grouped);
     const int skip = skip_small ? 1 : 0;
-    // the two groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
+    // the groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
                             segstate, st);
@@ -309,9 +310,14 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     for (int i = 0; i < n_seg && !any_big; ++i) any_big = !wt_small_unit(segs_host[i].T, segs_host[i].F);
     if (!any_big) return WT_OK;
     if (grouped) {
-        for (int k = 0; k < n_groups; ++k)
+        for (int k = 0; k < n_groups; ++k) {
+            bool big_here = !skip_small;   // (a group whose units all went to the fused tail kernel needs no column pass)
+            for (int i = groups[k].lo; i < groups[k].lo + groups[k].n && !big_here; ++i)
+                big_here = !wt_small_unit(segs_host[i].T, segs_host[i].F);
+            if (!big_here) continue;
             hipLaunchKernelGGL(colnorm_kernel, dim3((groups[k].maxF + 63) / 64, (groups[k].n + 7) & ~7), dim3(64 * CN_WAVES), 0, st,
                                cost, segs_dev, segstate, groups[k].lo, groups[k].n, skip);
+        }
     } else {
         hipLaunchKernelGGL(colnorm_kernel, dim3((maxF + 63) / 64, (n_seg + 7) & ~7), dim3(64 * CN_WAVES), 0, st, cost, segs_dev,
                            segstate, 0, n_seg, skip);

@@ -187,14 +187,24 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
         mx = wave_max_dpp(mx);
         const f2 mx2 = (f2){mx, mx};
         f2 e[C / 2];
-        f2 s2 = (f2){0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < C / 2; ++q) {
             const f2 t = ((f2){m[2 * q], m[2 * q + 1]} - mx2) * cexp;
             e[q] = (f2){__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};   // (masked: exp2(-1.4e30) = 0)
-            s2 += e[q];
         }
-        const float s = wave_sum_dpp(s2.x + s2.y);
+        // The softmax denominator is summed QUAD by quad of four consecutive frames, (e0 + e2) + (e1 + e3), a lane's quads
+        // in order, then the wave tree of wave_sum_dpp.  For a row of F <= 256 frames this is the SAME binary tree in the
+        // 4- and in the 8-elements-per-lane instantiation (quad index bits 0, 1, ... 5 in that order; lanes / quads beyond
+        // the row contribute exact zeros), so a short unit's row does not depend on whether its batch also holds a
+        // (256, 512] unit -- the one case in which units of two F classes share a launch (plan_groups).
+        float lane_sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < C / 4; ++k) {
+            const f2 p = e[2 * k] + e[2 * k + 1];
+            const float qs = p.x + p.y;
+            lane_sum = k == 0 ? qs : lane_sum + qs;
+        }
+        const float s = wave_sum_dpp(lane_sum);
         const float inv = 1.0f / s;
         const f2 inv2 = (f2){inv, inv};
 #pragma unroll
