@@ -30,35 +30,22 @@
 
 namespace wt {
 
-// C = elements per lane; an instantiation can serve any F <= C*64 (the launch passes the F range it is used for).
-// EXACT: every unit of the launch has (C-4)*64 < F <= C*64 (single-class launch): the compiler is told, and drops the
-// per-chunk guards of the first C-4 row chunks (measured: 0.106 vs 0.124 ms on the K-full cost stage).
-template <int C, typename QT, bool EXACT>
-__global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
-                                                      const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                      float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
-                                                      int f_lo, int f_hi) {
+// One token row of one unit: the head mean of softmax(median9(.)) -> cost[t, :].  ONE WAVE; `lds` = this wave's two row
+// buffers.  C = elements per lane; an instantiation can serve any F <= C*64.
+template <int C, typename QT>
+__device__ __forceinline__ void rowmean_row(const QT *__restrict__ qk, const wt_seg_desc &d, int t, const int32_t *__restrict__ head_idx,
+                                            int n_heads, float qk_scale, float *__restrict__ cost, float (*lds)[RowBuf<C, QT>::BUF],
+                                            int lane) {
     constexpr int CAP = C * 64;
-    constexpr int BUF = RowBuf<C, QT>::BUF;                        // per wave: double-buffered row (wt_cost_core.h)
-    __shared__ __attribute__((aligned(16))) float lds[4][2][BUF];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int unit = unit0 + blockIdx.y;
-    const wt_seg_desc d = segs[unit];
+    constexpr int BUF = RowBuf<C, QT>::BUF;
     const int F = d.F;
-    const int t = blockIdx.x * 4 + wave;
-    if (F <= f_lo || F > f_hi || t >= d.T) return;  // wave-uniform; the host guarantees f_hi <= CAP
-    if (EXACT) __builtin_assume(F > (C - 4) * 64);
-    if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
-
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     f2 acc[C / 2];
-    head_sum_row<C, QT>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds[wave], lane, acc);
+    head_sum_row<C, QT>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds, lane, acc);
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
     const float nh = (float)n_heads;
-    float *xs = &lds[wave][0][0];   // (fp16: the transposition spans both row buffers -- 2 * BUF >= CAP floats; all copies have landed)
+    float *xs = &lds[0][0];   // (fp16: the transposition spans both row buffers -- 2 * BUF >= CAP floats; all copies have landed)
     static_assert(2 * BUF >= CAP, "the output transposition fits the wave's two row buffers");
     wave_lds_fence();
     float4 *op = reinterpret_cast<float4 *>(xs + lane * C);
@@ -79,6 +66,66 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
         const int f = k * 64 + lane;
         if (f < F) out[f] = xs[f];
     }
+}
+
+// The launch of ONE F class (or of classes 0 + 1 together: plan_groups).
+// EXACT: every unit of the launch has (C-4)*64 < F <= C*64 (single-class launch): the compiler is told, and drops the
+// per-chunk guards of the first C-4 row chunks (measured: 0.106 vs 0.124 ms on the K-full cost stage).
+template <int C, typename QT, bool EXACT>
+__global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
+                                                      const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
+                                                      float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
+                                                      int f_lo, int f_hi) {
+    __shared__ __attribute__((aligned(16))) float lds[4][2][RowBuf<C, QT>::BUF];   // per wave: double-buffered row (wt_cost_core.h)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int unit = unit0 + blockIdx.y;
+    const wt_seg_desc d = segs[unit];
+    const int F = d.F;
+    const int t = blockIdx.x * 4 + wave;
+    if (F <= f_lo || F > f_hi || t >= d.T) return;  // wave-uniform; the host guarantees f_hi <= CAP
+    if (EXACT) __builtin_assume(F > (C - 4) * 64);
+    if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
+    rowmean_row<C, QT>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane);
+}
+
+// A SMALL batch that holds several F classes (the reference's per-segment units: a handful of segments per 30 s window,
+// any mix of lengths) is launch-bound: every rowmean launch costs its eight sequential head fetches (~12 us) however few
+// rows it has.  This kernel serves EVERY class in one launch: each workgroup runs the body of its own unit's class (the
+// same code, hence the same bits, as that class's own launch).  It carries the registers and the LDS of the largest
+// body (two workgroups per CU), which is why large batches keep one launch per class.
+template <typename QT>
+__global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
+                                                          const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
+                                                          float *__restrict__ cost, unsigned *__restrict__ segstate, int merge01) {
+    __shared__ __attribute__((aligned(16))) float raw[4 * 2 * RowBuf<28, float>::BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int unit = blockIdx.y;
+    const wt_seg_desc d = segs[unit];
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= d.T) return;   // wave-uniform
+    if (t == 0 && lane == 0) segstate[unit] = 0u;
+    int cls = (d.F + 255) / 256 - 1;
+    if (cls == 0 && merge01) cls = 1;   // (what a batch with both short classes gets from its shared launch: same bits)
+#define WT_ROW_CASE(CI)                                                                                              \
+    case CI: {                                                                                                        \
+        constexpr int BUF = RowBuf<4 * (CI + 1), QT>::BUF;                                                            \
+        rowmean_row<4 * (CI + 1), QT>(qk, d, t, head_idx, n_heads, qk_scale, cost,                                    \
+                                      reinterpret_cast<float (*)[BUF]>(raw + (size_t)wave * 2 * BUF), lane);          \
+        break;                                                                                                        \
+    }
+    switch (cls) {
+        WT_ROW_CASE(0)
+        WT_ROW_CASE(1)
+        WT_ROW_CASE(2)
+        WT_ROW_CASE(3)
+        WT_ROW_CASE(4)
+        WT_ROW_CASE(5)
+        default:
+        WT_ROW_CASE(6)
+    }
+#undef WT_ROW_CASE
 }
 
 // 64 columns x all T token rows per workgroup of 16 waves: wave w owns rows w, w+16, ... (<= 16 rows for
@@ -292,6 +339,26 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     LaunchGroup groups[MAX_GROUPS];
     const int n_groups = plan_groups(cls, groups, grouped);
     const int skip = skip_small ? 1 : 0;
+    // A small batch of several classes: one launch for all of them (rowmean_any_kernel).  "Small" = fewer token rows
+    // than two workgroups per CU hold at once; the bits are those of the per-class launches either way.
+    long long total_rows = 0;
+    int maxT = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        total_rows += segs_host[i].T;
+        if (segs_host[i].T > maxT) maxT = segs_host[i].T;
+    }
+    if (n_groups > 1 && total_rows <= 8LL * 256 * 2 && (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
+        const dim3 grid((maxT + 3) / 4, n_seg);
+        const int merge01 = (cls[0].any && cls[1].any) ? 1 : 0;
+        if (qk_dtype == WT_DTYPE_F32)
+            hipLaunchKernelGGL(rowmean_any_kernel<float>, grid, dim3(256), 0, st, (const float *)qk, segs_dev, head_idx, n_heads,
+                               qk_scale, cost, segstate, merge01);
+        else
+            hipLaunchKernelGGL(rowmean_any_kernel<__half>, grid, dim3(256), 0, st, (const __half *)qk, segs_dev, head_idx, n_heads,
+                               qk_scale, cost, segstate, merge01);
+        WT_HIP(hipGetLastError());
+        rc = WT_OK;
+    } else
     // the groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
