@@ -162,9 +162,13 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
  *   flags : WT_ALIGN_KEEP_COST             cost[] holds the final matrix of every unit (without it the small units
  *                                          leave only their head-mean rows there); wt_disfluency_batch needs it
  *           WT_ALIGN_NO_FUSED_SMALL_UNITS  every unit through the batched kernels (A/B measurements, tests)
+ *           WT_ALIGN_ROWS_PER_CLASS        the row pass as one pipelined launch per F class even for a small batch
+ *                                          (a small batch otherwise gets ONE launch that fetches eight heads at once;
+ *                                          same bits either way: A/B measurements, tests)
  * wt_align_batch(...) = wt_align_batch_v3(..., WT_ALIGN_KEEP_COST, stream). */
 #define WT_ALIGN_KEEP_COST 1
 #define WT_ALIGN_NO_FUSED_SMALL_UNITS 2
+#define WT_ALIGN_ROWS_PER_CLASS 4
 int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                       const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, int flags, void *stream);

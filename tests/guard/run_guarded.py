@@ -274,6 +274,8 @@ CASES = {
     "odd_units_f16": lambda m: case_odd_units(m, torch.float16),
     "odd_units_f32_batched_only": lambda m: case_odd_units(m, torch.float32, flags=3),
     "odd_units_f16_batched_only": lambda m: case_odd_units(m, torch.float16, flags=3),
+    "odd_units_f32_rows_per_class": lambda m: case_odd_units(m, torch.float32, flags=5),
+    "odd_units_f16_rows_per_class": lambda m: case_odd_units(m, torch.float16, flags=5),
     "logprob": case_logprob,
     "logmel": case_logmel,
     "capture": case_capture,

@@ -397,6 +397,12 @@ def test_fused_small_units_equal_the_batched_kernels(dtype):
         assert np.array_equal(fused["jumps"][j0:j0 + T + 1].cpu().numpy(), O.jumps_from_path(r.index1s, r.index2s)), (T, F)
         n_small += int(L.small_unit(T, F))
     assert n_small > 60 and n_small < len(shapes)
+    # the row pass as one launch per F class (what large batches get) instead of the small batch's single launch: same bits
+    per_class = _align_units(shapes, dtype, L.WT_ALIGN_KEEP_COST | L.WT_ALIGN_ROWS_PER_CLASS)
+    for d in per_class["descs"]:
+        c0, n = int(d["cost_offset"]), int(d["T"]) * int(d["F"])
+        assert torch.equal(per_class["cost"][c0:c0 + n], fused["cost"][c0:c0 + n]), (int(d["T"]), int(d["F"]))
+    assert torch.equal(per_class["jumps"], fused["jumps"])
     # without WT_ALIGN_KEEP_COST the fused units leave no matrix behind, the others do; jumps are the same
     lean = _align_units(shapes, dtype, 0, want_path=False)
     assert torch.equal(lean["jumps"], plain["jumps"])

@@ -79,7 +79,7 @@ void scratch_forget_tags() {
 }
 
 int cost_batch(const void *, int, const wt_seg_desc *, const wt_seg_desc *, int, const int32_t *, int, int, float, float *,
-               bool, hipStream_t);
+               bool, bool, hipStream_t);
 int dtw_batch(const float *, const wt_seg_desc *, const wt_seg_desc *, int, int, int32_t *, int32_t *, int32_t *, int32_t *,
               double *, bool, hipStream_t);
 int align_small_tail(const wt_seg_desc *, const wt_seg_desc *, int, float *, bool, int32_t *, int32_t *, int32_t *, int32_t *,
@@ -135,7 +135,7 @@ int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, i
 
 int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                   const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, void *stream) {
-    return wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, false,
+    return wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, false, false,
                           (hipStream_t)stream);
 }
 
@@ -164,7 +164,7 @@ int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host
         for (int s = 0; s < n_seg && !any_small; ++s) any_small = wt::wt_small_unit(segs_host[s].T, segs_host[s].F);
     // (argument checks: the batched entry points make them, also when every unit is small)
     int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, any_small,
-                            (hipStream_t)stream);
+                            (flags & WT_ALIGN_ROWS_PER_CLASS) != 0, (hipStream_t)stream);
     if (rc) return rc;
     if (!jumps || (!path_i != !path_j)) {
         wt::set_error("wt_align_batch: null pointer or bad count");

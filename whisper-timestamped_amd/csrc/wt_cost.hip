@@ -30,9 +30,9 @@
 
 namespace wt {
 
-// One token row of one unit: the head mean of softmax(median9(.)) -> cost[t, :].  ONE WAVE; `lds` = this wave's two row
-// buffers.  C = elements per lane; an instantiation can serve any F <= C*64.
-template <int C, typename QT>
+// One token row of one unit: the head mean of softmax(median9(.)) -> cost[t, :].  ONE WAVE; `lds` = this wave's NB row
+// buffers (wt_cost_core.h).  C = elements per lane; an instantiation can serve any F <= C*64.
+template <int C, typename QT, int NB = 2>
 __device__ __forceinline__ void rowmean_row(const QT *__restrict__ qk, const wt_seg_desc &d, int t, const int32_t *__restrict__ head_idx,
                                             int n_heads, float qk_scale, float *__restrict__ cost, float (*lds)[RowBuf<C, QT>::BUF],
                                             int lane) {
@@ -41,7 +41,7 @@ __device__ __forceinline__ void rowmean_row(const QT *__restrict__ qk, const wt_
     const int F = d.F;
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     f2 acc[C / 2];
-    head_sum_row<C, QT>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds, lane, acc);
+    head_sum_row<C, QT, NB>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds, lane, acc);
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
     const float nh = (float)n_heads;
@@ -89,16 +89,18 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     rowmean_row<C, QT>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane);
 }
 
-// A SMALL batch that holds several F classes (the reference's per-segment units: a handful of segments per 30 s window,
-// any mix of lengths) is launch-bound: every rowmean launch costs its eight sequential head fetches (~12 us) however few
-// rows it has.  This kernel serves EVERY class in one launch: each workgroup runs the body of its own unit's class (the
-// same code, hence the same bits, as that class's own launch).  It carries the registers and the LDS of the largest
-// body (two workgroups per CU), which is why large batches keep one launch per class.
+// A SMALL batch (the reference's per-segment units: a handful of segments per 30 s window, any mix of lengths) is bound by
+// launches and by latency: every rowmean launch lasts its eight sequential head fetches (~12 us) however few rows it
+// has.  This kernel serves EVERY class in one launch -- each workgroup runs the body of its own unit's class: the same
+// code, hence the same bits, as that class's own launch -- and the short classes (F <= 512) fetch the rows of eight heads
+// at once (one memory latency per eight heads instead of eight).  It carries the registers and the LDS of its largest
+// body (two workgroups per CU), which is why large batches keep one pipelined launch per class.
+constexpr int ANY_WAVE_FLOATS = 8 * RowBuf<8, float>::BUF > 2 * RowBuf<28, float>::BUF ? 8 * RowBuf<8, float>::BUF : 2 * RowBuf<28, float>::BUF;
 template <typename QT>
 __global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                           const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
                                                           float *__restrict__ cost, unsigned *__restrict__ segstate, int merge01) {
-    __shared__ __attribute__((aligned(16))) float raw[4 * 2 * RowBuf<28, float>::BUF];
+    __shared__ __attribute__((aligned(16))) float raw[4 * ANY_WAVE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int unit = blockIdx.y;
@@ -108,22 +110,23 @@ __global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__
     if (t == 0 && lane == 0) segstate[unit] = 0u;
     int cls = (d.F + 255) / 256 - 1;
     if (cls == 0 && merge01) cls = 1;   // (what a batch with both short classes gets from its shared launch: same bits)
-#define WT_ROW_CASE(CI)                                                                                              \
+#define WT_ROW_CASE(CI, NBUF)                                                                                        \
     case CI: {                                                                                                        \
         constexpr int BUF = RowBuf<4 * (CI + 1), QT>::BUF;                                                            \
-        rowmean_row<4 * (CI + 1), QT>(qk, d, t, head_idx, n_heads, qk_scale, cost,                                    \
-                                      reinterpret_cast<float (*)[BUF]>(raw + (size_t)wave * 2 * BUF), lane);          \
+        static_assert(NBUF * BUF <= ANY_WAVE_FLOATS, "the wave's share of the LDS holds its row buffers");            \
+        rowmean_row<4 * (CI + 1), QT, NBUF>(qk, d, t, head_idx, n_heads, qk_scale, cost,                              \
+                                            reinterpret_cast<float (*)[BUF]>(raw + (size_t)wave * ANY_WAVE_FLOATS), lane); \
         break;                                                                                                        \
     }
     switch (cls) {
-        WT_ROW_CASE(0)
-        WT_ROW_CASE(1)
-        WT_ROW_CASE(2)
-        WT_ROW_CASE(3)
-        WT_ROW_CASE(4)
-        WT_ROW_CASE(5)
+        WT_ROW_CASE(0, 8)
+        WT_ROW_CASE(1, 8)
+        WT_ROW_CASE(2, 2)
+        WT_ROW_CASE(3, 2)
+        WT_ROW_CASE(4, 2)
+        WT_ROW_CASE(5, 2)
         default:
-        WT_ROW_CASE(6)
+        WT_ROW_CASE(6, 2)
     }
 #undef WT_ROW_CASE
 }
@@ -308,7 +311,7 @@ static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, 
 
 int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, bool skip_small,
-               hipStream_t st) {
+               bool rows_per_class, hipStream_t st) {
     if (!qk || !segs_host || !segs_dev || !head_idx || !cost || n_seg < 0 || n_heads <= 0) {
         set_error("wt_cost_batch: null pointer or bad count");
         return WT_E_BADARG;
@@ -339,15 +342,15 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     LaunchGroup groups[MAX_GROUPS];
     const int n_groups = plan_groups(cls, groups, grouped);
     const int skip = skip_small ? 1 : 0;
-    // A small batch of several classes: one launch for all of them (rowmean_any_kernel).  "Small" = fewer token rows
-    // than two workgroups per CU hold at once; the bits are those of the per-class launches either way.
+    // A small batch: one launch for all of its classes, eight heads fetched at once (rowmean_any_kernel).  "Small" = fewer
+    // token rows than two workgroups per CU hold at once; the bits are those of the per-class launches either way.
     long long total_rows = 0;
     int maxT = 0;
     for (int i = 0; i < n_seg; ++i) {
         total_rows += segs_host[i].T;
         if (segs_host[i].T > maxT) maxT = segs_host[i].T;
     }
-    if (n_groups > 1 && total_rows <= 8LL * 256 * 2 && (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
+    if (!rows_per_class && total_rows <= 8LL * 256 * 2 && (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
         const dim3 grid((maxT + 3) / 4, n_seg);
         const int merge01 = (cls[0].any && cls[1].any) ? 1 : 0;
         if (qk_dtype == WT_DTYPE_F32)

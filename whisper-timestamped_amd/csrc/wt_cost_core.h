@@ -78,7 +78,11 @@ struct RowBuf {
 };
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int C, typename QT>
+// NB = row buffers the wave owns.  NB = 2: head a+1 streams in while head a is being consumed (a launch with thousands of
+// waves hides the rest of the latency).  NB > 2 (small launches, where a wave's fetches are what the kernel waits for): the
+// rows of up to NB heads are fetched AT ONCE, one memory latency for all of them, then consumed one after the other.  The
+// arithmetic and the order of accumulation over heads are the same: same bits.
+template <int C, typename QT, int NB = 2>
 __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride, const int32_t *__restrict__ head_idx,
                                              int n_heads, int F, float qk_scale, float (*lds)[RowBuf<C, QT>::BUF], int lane,
                                              f2 (&acc)[C / 2]) {
@@ -101,27 +105,27 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
     const int tail0 = F & ~3, ntail = (!HALF && F >= 4) ? (F & 3) : 0;
     // fp16: every head's row of this token starts at the same parity (head_stride elements apart: the shift is
     // recomputed per head, it is one AND)
-    float tail = 0.f;
-    unsigned short tailh = 0;
-    int sh = 0;
-    auto stage = [&](int a) __attribute__((always_inline)) {
+    constexpr int NT = NB > 2 ? NB : 1;      // (the pipelined form has one row in flight: one set of tail registers)
+    float tail[NT];
+    unsigned short tailh[NT];
+    int shv[NT];
+    auto stage = [&](int a, int buf, int slot) __attribute__((always_inline)) {
         const QT *src = row0 + (int64_t)head_idx[a] * head_stride;
         if constexpr (HALF) {
-            sh = (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 1);
-            tailh = stage_row_h<C>(src, reinterpret_cast<unsigned short *>(lds[a & 1]), F, sh, lane);
+            shv[slot] = (int)((reinterpret_cast<uintptr_t>(src) >> 1) & 1);
+            tailh[slot] = stage_row_h<C>(src, reinterpret_cast<unsigned short *>(lds[buf]), F, shv[slot], lane);
         } else {
-            tail = stage_row<C>(src, lds[a & 1], F, nch, lane);
+            tail[slot] = stage_row<C>(src, lds[buf], F, nch, lane);
         }
     };
-    stage(0);
-    for (int a = 0; a < n_heads; ++a) {
-        float x[C + 8];
-        wait_vmcnt0();                 // head a's row has landed in LDS
+    // the landed row of buffer `buf` -> registers x[0 .. C+8) (this lane's C elements + 4 of halo on each side)
+    auto fetch = [&](int buf, int slot, float (&x)[C + 8]) __attribute__((always_inline)) {
         wave_lds_fence();
         if constexpr (HALF) {
-            unsigned short *hs = reinterpret_cast<unsigned short *>(lds[a & 1]);
+            const int sh = shv[slot];
+            unsigned short *hs = reinterpret_cast<unsigned short *>(lds[buf]);
             const int Fh = F + sh;
-            if (lane < (Fh & 7)) hs[8 + (Fh & ~7) + lane] = tailh;   // (the group that straddles the end of the row)
+            if (lane < (Fh & 7)) hs[8 + (Fh & ~7) + lane] = tailh[slot];   // (the group that straddles the end of the row)
             wave_lds_fence();
             if (lane < 8) {
                 const unsigned short hv = hs[8 + sh + hsrc];
@@ -147,8 +151,8 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
                 x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
             }
         } else {
-            float *xs = lds[a & 1];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
-            if (lane < ntail) xs[4 + tail0 + lane] = tail;   // (the group that straddles the end of the row)
+            float *xs = lds[buf];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
+            if (lane < ntail) xs[4 + tail0 + lane] = tail[slot];   // (the group that straddles the end of the row)
             wave_lds_fence();
             if (lane < 8) {
                 const float hv = xs[4 + hsrc];
@@ -162,10 +166,9 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
                 x[4 * k + 0] = r.x; x[4 * k + 1] = r.y; x[4 * k + 2] = r.z; x[4 * k + 3] = r.w;
             }
         }
-        // Row a now lives in registers: start streaming head a+1 into the other buffer; it lands while
-        // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
-        // that follows an LDS-DMA, which would serialise the copy with the reads.)
-        if (a + 1 < n_heads) stage(a + 1);
+    };
+    // median-9, softmax over the window, acc += softmax
+    auto fold = [&](const float (&x)[C + 8]) __attribute__((always_inline)) {
         // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
         float lo[C + 6], mi[C + 6], hi[C + 6];
 #pragma unroll
@@ -209,9 +212,38 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
         const f2 inv2 = (f2){inv, inv};
 #pragma unroll
         for (int q = 0; q < C / 2; ++q) acc[q] = __builtin_elementwise_fma(e[q], inv2, acc[q]);
-    }
+    };
 
+    if constexpr (NB == 2) {
+        stage(0, 0, 0);
+        for (int a = 0; a < n_heads; ++a) {
+            float x[C + 8];
+            wait_vmcnt0();                 // head a's row has landed in LDS
+            fetch(a & 1, 0, x);
+            // Row a now lives in registers: start streaming head a+1 into the other buffer; it lands while
+            // the VALU work below runs.  (Issued AFTER the LDS reads: hipcc drains vmcnt before any ds_read
+            // that follows an LDS-DMA, which would serialise the copy with the reads.)
+            if (a + 1 < n_heads) stage(a + 1, (a + 1) & 1, 0);
+            fold(x);
+        }
+    } else {
+        for (int a0 = 0; a0 < n_heads; a0 += NB) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (a0 + k < n_heads) stage(a0 + k, k, k);   // (wave-uniform)
+            wait_vmcnt0();                 // all of them have landed
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (a0 + k < n_heads) {
+                    float x[C + 8];
+                    fetch(k, k, x);
+                    fold(x);
+                }
+        }
+    }
 }
+
+
 
 // mean over heads (torch CPU: sum then div): x * (1/n) == x / n exactly for a power of two
 __device__ __forceinline__ float head_mean(float sum, int n_heads) {

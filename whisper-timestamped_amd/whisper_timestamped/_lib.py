@@ -33,7 +33,7 @@ EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dt
            "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
 ABI_VERSION = 3
-WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS = 1, 2
+WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS, WT_ALIGN_ROWS_PER_CLASS = 1, 2, 4
 
 
 class WtError(RuntimeError):
