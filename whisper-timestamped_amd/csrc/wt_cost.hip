@@ -96,16 +96,30 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 // at once (one memory latency per eight heads instead of eight).  It carries the registers and the LDS of its largest
 // body (two workgroups per CU), which is why large batches keep one pipelined launch per class.
 constexpr int ANY_WAVE_FLOATS = 8 * RowBuf<8, float>::BUF > 2 * RowBuf<28, float>::BUF ? 8 * RowBuf<8, float>::BUF : 2 * RowBuf<28, float>::BUF;
+// Which workgroup serves which rows: first[u] = index of unit u's first workgroup (four token rows each), first[n] =
+// the grid size.  Passed BY VALUE (kernel arguments): a grid of exactly sum(ceil(T/4)) workgroups instead of
+// n_units x ceil(maxT/4) mostly empty ones, each of which would fetch its descriptor only to find it has no rows
+// (160 real-shape units: 640 workgroups instead of 2560 -- five dispatch rounds of this kernel's LDS footprint).
+constexpr int ANY_MAX_UNITS = 512;
+struct WgTable {
+    unsigned short first[ANY_MAX_UNITS + 1];
+};
 template <typename QT>
 __global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
                                                           const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
-                                                          float *__restrict__ cost, unsigned *__restrict__ segstate, int merge01) {
+                                                          float *__restrict__ cost, unsigned *__restrict__ segstate, int merge01,
+                                                          int n_units, const WgTable table) {
     __shared__ __attribute__((aligned(16))) float raw[4 * ANY_WAVE_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int unit = blockIdx.y;
+    int lo = 0, hi = n_units;                       // the unit whose workgroup range holds blockIdx.x (uniform: scalar unit)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (table.first[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int unit = lo;
     const wt_seg_desc d = segs[unit];
-    const int t = blockIdx.x * 4 + wave;
+    const int t = ((int)blockIdx.x - (int)table.first[unit]) * 4 + wave;
     if (t >= d.T) return;   // wave-uniform
     if (t == 0 && lane == 0) segstate[unit] = 0u;
     int cls = (d.F + 255) / 256 - 1;
@@ -345,20 +359,23 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     // A small batch: one launch for all of its classes, eight heads fetched at once (rowmean_any_kernel).  "Small" = fewer
     // token rows than two workgroups per CU hold at once; the bits are those of the per-class launches either way.
     long long total_rows = 0;
-    int maxT = 0;
-    for (int i = 0; i < n_seg; ++i) {
-        total_rows += segs_host[i].T;
-        if (segs_host[i].T > maxT) maxT = segs_host[i].T;
-    }
-    if (!rows_per_class && total_rows <= 8LL * 256 * 2 && (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
-        const dim3 grid((maxT + 3) / 4, n_seg);
+    for (int i = 0; i < n_seg; ++i) total_rows += segs_host[i].T;
+    if (!rows_per_class && total_rows <= 8LL * 256 * 2 && n_seg <= ANY_MAX_UNITS &&
+        (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
+        WgTable table;
+        unsigned n_wg = 0;
+        for (int i = 0; i < n_seg; ++i) {
+            table.first[i] = (unsigned short)n_wg;
+            n_wg += (unsigned)(segs_host[i].T + 3) / 4;
+        }
+        table.first[n_seg] = (unsigned short)n_wg;     // (total_rows <= 4096: at most 4096 / 4 + n_seg workgroups)
         const int merge01 = (cls[0].any && cls[1].any) ? 1 : 0;
         if (qk_dtype == WT_DTYPE_F32)
-            hipLaunchKernelGGL(rowmean_any_kernel<float>, grid, dim3(256), 0, st, (const float *)qk, segs_dev, head_idx, n_heads,
-                               qk_scale, cost, segstate, merge01);
+            hipLaunchKernelGGL(rowmean_any_kernel<float>, dim3(n_wg), dim3(256), 0, st, (const float *)qk, segs_dev, head_idx, n_heads,
+                               qk_scale, cost, segstate, merge01, n_seg, table);
         else
-            hipLaunchKernelGGL(rowmean_any_kernel<__half>, grid, dim3(256), 0, st, (const __half *)qk, segs_dev, head_idx, n_heads,
-                               qk_scale, cost, segstate, merge01);
+            hipLaunchKernelGGL(rowmean_any_kernel<__half>, dim3(n_wg), dim3(256), 0, st, (const __half *)qk, segs_dev, head_idx,
+                               n_heads, qk_scale, cost, segstate, merge01, n_seg, table);
         WT_HIP(hipGetLastError());
         rc = WT_OK;
     } else
