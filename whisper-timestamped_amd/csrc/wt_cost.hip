@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
 // has.  This kernel serves EVERY class in one launch -- each workgroup runs the body of its own unit's class: the same
 // code, hence the same bits, as that class's own launch -- and the short classes (F <= 512) fetch the rows of eight heads
 // at once (one memory latency per eight heads instead of eight).  It carries the registers and the LDS of its largest
-// body (two workgroups per CU), which is why large batches keep one pipelined launch per class.
-constexpr int ANY_WAVE_FLOATS = 8 * RowBuf<8, float>::BUF > 2 * RowBuf<28, float>::BUF ? 8 * RowBuf<8, float>::BUF : 2 * RowBuf<28, float>::BUF;
+// body, which is why it stops at F <= 1024 (four workgroups per CU) and why large batches keep one pipelined launch per class.
+constexpr int ANY_MAX_CLASS = 3;   // F <= 1024: four workgroups of this kernel share a CU; longer units (rare among per-segment units) keep their class's own launch
+constexpr int ANY_WAVE_FLOATS = 8 * RowBuf<4, float>::BUF;   // = 4 buffers of the 8-element class, 2 of the 16-element class
 // Which workgroup serves which rows: first[u] = index of unit u's first workgroup (four token rows each), first[n] =
 // the grid size.  Passed BY VALUE (kernel arguments): a grid of exactly sum(ceil(T/4)) workgroups instead of
 // n_units x ceil(maxT/4) mostly empty ones, each of which would fetch its descriptor only to find it has no rows
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__
     const int unit = lo;
     const wt_seg_desc d = segs[unit];
     const int t = ((int)blockIdx.x - (int)table.first[unit]) * 4 + wave;
-    if (t >= d.T) return;   // wave-uniform
+    if (t >= d.T || d.F > (ANY_MAX_CLASS + 1) * 256) return;   // wave-uniform (longer units: their class's own launch)
     if (t == 0 && lane == 0) segstate[unit] = 0u;
     int cls = (d.F + 255) / 256 - 1;
     if (cls == 0 && merge01) cls = 1;   // (what a batch with both short classes gets from its shared launch: same bits)
@@ -134,13 +135,10 @@ __global__ __launch_bounds__(256) void rowmean_any_kernel(const QT *__restrict__
     }
     switch (cls) {
         WT_ROW_CASE(0, 8)
-        WT_ROW_CASE(1, 8)
+        WT_ROW_CASE(1, 4)
         WT_ROW_CASE(2, 2)
-        WT_ROW_CASE(3, 2)
-        WT_ROW_CASE(4, 2)
-        WT_ROW_CASE(5, 2)
         default:
-        WT_ROW_CASE(6, 2)
+        WT_ROW_CASE(3, 2)
     }
 #undef WT_ROW_CASE
 }
@@ -378,6 +376,18 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
                                n_heads, qk_scale, cost, segstate, merge01, n_seg, table);
         WT_HIP(hipGetLastError());
         rc = WT_OK;
+        LaunchGroup longer[MAX_GROUPS];
+        int n_longer = 0;
+        for (int k = 0; k < n_groups; ++k)
+            if (groups[k].ci > ANY_MAX_CLASS) longer[n_longer++] = groups[k];
+        if (n_longer) {
+            if (qk_dtype == WT_DTYPE_F32)
+                rc = launch_rowmean((const float *)qk, segs_dev, n_seg, longer, n_longer, grouped, head_idx, n_heads, qk_scale, cost,
+                                    segstate, st);
+            else
+                rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, longer, n_longer, grouped, head_idx, n_heads, qk_scale, cost,
+                                    segstate, st);
+        }
     } else
     // the groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
