@@ -956,14 +956,22 @@ def run_child(role, extra, timeout_s, env=None):
     os.unlink(path)
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--role", role, "--out", path] + list(extra)
     err = None
+    # its own session: a leg that has to be stopped takes its own children (worker processes) with it
+    proc = subprocess.Popen(cmd, stdout=sys.stderr, env=env, start_new_session=True)      # children never write to stdout
     try:
-        rc = subprocess.run(cmd, stdout=sys.stderr, timeout=timeout_s, env=env).returncode      # children never write to stdout
+        rc = proc.wait(timeout=timeout_s)
         if rc < 0:
             err = f"signal {-rc}"
         elif rc != 0:
             err = f"exit {rc}"
     except subprocess.TimeoutExpired:
         err = f"timeout after {timeout_s} s"
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
     res = None
     if os.path.exists(path):
         try:

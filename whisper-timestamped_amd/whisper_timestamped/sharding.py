@@ -256,6 +256,7 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, audios, order, options, barrier, queue,
                                                     on_item, warmup)) for r in range(n_workers)]
     for p in procs:
+        p.daemon = True           # (a worker never outlives the process that asked for it)
         p.start()
     got, slowest = {}, 0.0
     try:
