@@ -30,3 +30,26 @@ def script_clip(index):
     from golden import make_golden_transcribe as G
     segs = [(s, [None] * n, e) for s, n, e in SEGMENTS]
     set_script(Script([G.window_script(50364, 50257, segs, "eot")]))
+
+
+class _Patch:
+    """the two methods of pytest's monkeypatch that cpu_kernel_standin.install uses (a worker process has no fixture)"""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+_STANDIN = False
+
+
+def script_clip_cpu(index):
+    """CPU host-logic tests: the oracle-backed stand-in for the kernels (tests/cpu_kernel_standin.py), installed once per
+    worker process, then the scripted transcript."""
+    global _STANDIN
+    if not _STANDIN:
+        import torch
+        import cpu_kernel_standin
+        torch.set_num_threads(4)          # (several workers share the host's cores)
+        cpu_kernel_standin.install(_Patch())
+        _STANDIN = True
+    script_clip(index)

@@ -217,3 +217,31 @@ def test_islands_job_two_ranks(tmp_path):
     out = tmp_path / "islands.txt"
     mp.spawn(_islands_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     assert out.read_text().startswith("ok ")
+
+
+def test_transcribe_many_two_worker_processes_on_the_cpu(monkeypatch):
+    """sharding.transcribe_many's process plumbing (spawned workers, largest-first dealing, common start, results back in
+    the caller's order) with the kernels replaced by the oracle-backed stand-in: the dictionaries of serial transcribe()
+    calls in this process.  The same comparison with the real kernels: tests/test_gpu_transcribe.py."""
+    import torch
+    import many_helper as H
+    import cpu_kernel_standin
+    import whisper_timestamped as wt
+    from whisper_double.decoding import set_script
+    from whisper_timestamped.sharding import transcribe_many
+    g = torch.Generator().manual_seed(11)
+    audios = [(0.05 * torch.randn(n, generator=g)).float() for n in (30 * 16000, 17 * 16000)]
+    cpu_kernel_standin.install(monkeypatch)
+    model = H.load_tiny("cpu")
+    serial = []
+    for k, a in enumerate(audios):
+        H.script_clip(k)
+        serial.append(wt.transcribe(model, a, language="en", fp16=False))
+    set_script(None)
+    many = transcribe_many(H.load_tiny, audios, workers_per_gpu=2, devices=["cpu"], on_item=H.script_clip_cpu, language="en",
+                           fp16=False)
+    assert len(many) == len(serial)
+    for a, b in zip(many, serial):
+        assert a["text"] == b["text"] and len(a["segments"]) == len(b["segments"]) > 0
+        for sa, sb in zip(a["segments"], b["segments"]):
+            assert sa["words"] == sb["words"]

@@ -214,8 +214,14 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
 # in, result dictionaries out.
 def _many_worker(rank, n_workers, devices, load_model, audios, order, options, barrier, out_queue, on_item, warmup):
     import time
+    import os
+    # W processes with the default intra-op thread count each (= every core of the host) spend their time fighting for
+    # cores (measured: 4 / 8 workers no faster than 2): the decode loop is one Python thread, give it a share of the host
+    torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(n_workers, 1))))
     dev = devices[rank % len(devices)]
-    torch.cuda.set_device(dev)
+    on_gpu = torch.device(dev).type == "cuda"      # (the CPU only ever appears in the host-logic tests)
+    if on_gpu:
+        torch.cuda.set_device(dev)
     from .transcribe import transcribe_timestamped
     model = load_model(dev)
     mine = order[rank]
@@ -223,7 +229,8 @@ def _many_worker(rank, n_workers, devices, load_model, audios, order, options, b
         if on_item is not None:
             on_item(mine[0])
         transcribe_timestamped(model, audios[mine[0]], **options)
-    torch.cuda.synchronize(dev)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     if barrier is not None:
         barrier.wait()
     t0 = time.perf_counter()
@@ -232,7 +239,8 @@ def _many_worker(rank, n_workers, devices, load_model, audios, order, options, b
         if on_item is not None:
             on_item(i)
         res.append((i, transcribe_timestamped(model, audios[i], **options)))
-    torch.cuda.synchronize(dev)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
     out_queue.put((rank, time.perf_counter() - t0, res))
 
 
