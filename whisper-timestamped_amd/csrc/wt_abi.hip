@@ -162,14 +162,13 @@ int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host
     bool any_small = false;
     if (fused && segs_host && n_seg > 0)
         for (int s = 0; s < n_seg && !any_small; ++s) any_small = wt::wt_small_unit(segs_host[s].T, segs_host[s].F);
-    // (argument checks: the batched entry points make them, also when every unit is small)
-    int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, any_small,
-                            (flags & WT_ALIGN_ROWS_PER_CLASS) != 0, (hipStream_t)stream);
-    if (rc) return rc;
-    if (!jumps || (!path_i != !path_j)) {
+    if (!jumps || (!path_i != !path_j)) {   // (before anything is launched; the batched entry points check the rest)
         wt::set_error("wt_align_batch: null pointer or bad count");
         return WT_E_BADARG;
     }
+    int rc = wt::cost_batch(qk, qk_dtype, segs_host, segs_dev, n_seg, head_idx, n_heads, medfilt_width, qk_scale, cost, any_small,
+                            (flags & WT_ALIGN_ROWS_PER_CLASS) != 0, (hipStream_t)stream);
+    if (rc) return rc;
     if (any_small) {
         rc = wt::align_small_tail(segs_host, segs_dev, n_seg, cost, (flags & WT_ALIGN_KEEP_COST) != 0, jumps, path_i, path_j,
                                   path_len, dist, (hipStream_t)stream);

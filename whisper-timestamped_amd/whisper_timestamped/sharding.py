@@ -252,6 +252,7 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     be picklable (a module-level function), as must `on_item(index)` (called in the worker before item `index`).
     Recordings are dealt to the workers largest-first by length.  Returns the result dictionaries in the order of
     `audios` (with `return_timing`: also the slowest worker's seconds between the common start and its last result)."""
+    import queue as queue_mod
     import torch.multiprocessing as mp
     from .naive import get_audio_tensor
     devices = list(devices) if devices is not None else [f"cuda:{k}" for k in range(torch.cuda.device_count())]
@@ -274,7 +275,7 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
                 try:
                     rank, seconds, res = queue.get(timeout=5.0)
                     break
-                except Exception:              # noqa: BLE001  (queue.Empty: is everybody still alive?)
+                except queue_mod.Empty:        # nothing yet: is everybody still alive?
                     dead = [p for p in procs if p.exitcode not in (None, 0)]
                     if dead:
                         raise RuntimeError(f"transcribe_many: a worker died (exit code {dead[0].exitcode})")
