@@ -1010,12 +1010,12 @@ def orchestrate(args):
     world = int(world_env or "1")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     inject = ["--inject-fault", ""]                        # a retried leg is not aborted again
-    out, err = run_child("kernel", [], 900)
+    out, err = run_child("kernel", [], 420)
     attempts = 1
     if (out is None or err) and world == 1:
         # A leg that died is run once more and the line says so: the number is reported, the fault is not hidden.
         first = {"error": err, "published_before_the_fault": sorted(out) if out else None}
-        out2, err2 = run_child("kernel", inject, 900)
+        out2, err2 = run_child("kernel", inject, 420)
         attempts = 2
         if out2 is not None and (out is None or not err2):
             out, err = out2, err2
@@ -1034,22 +1034,22 @@ def orchestrate(args):
     if world == 1 and not args.dry_run:
         fixed_shape = not WORKLOADS[args.workload].get("units_per_chunk")
         if not args.no_cpu_baseline and fixed_shape:       # rank 0 at N=1 only (fixed-shape workloads)
-            cpu, cerr = run_child("cpu", [], 600)
+            cpu, cerr = run_child("cpu", [], 300)
             out.update(cpu or {})
             if cerr:
                 out["cpu_baseline_error"] = cerr
         if args.e2e == "on" or (args.e2e == "auto" and args.workload == "kfull" and args.overlap == "none" and not args.graph):
-            e2e, e1 = run_child("e2e", ["--leg", "fp32"], 900)
+            e2e, e1 = run_child("e2e", ["--leg", "fp32"], 420)
             e2e = e2e or {}
             if e1:
                 e2e["error"] = e1
-            half, e2 = run_child("e2e", ["--leg", "fp16"], 900)
+            half, e2 = run_child("e2e", ["--leg", "fp16"], 420)
             half = half or {}
             half.pop("marker", None)
             e2e.update(half)
             if e2:
                 e2e["fp16_legs_error"] = e2
-            eff, e3 = run_child("e2e", ["--leg", "efficient"], 600)
+            eff, e3 = run_child("e2e", ["--leg", "efficient"], 300)
             eff = eff or {}
             eff.pop("marker", None)
             if e3:
