@@ -832,3 +832,29 @@ def test_cost_and_jumps_do_not_depend_on_the_batch(dtype):
         T, F, c0, j0 = int(d["T"]), int(d["F"]), int(d["cost_offset"]), int(d["jumps_offset"])
         assert torch.equal(cost[c0:c0 + T * F], c_alone), f"cost of unit (T={T}, F={F}) depends on the batch"
         assert torch.equal(jumps[j0:j0 + T + 1], j_alone), (T, F)
+
+
+def test_fused_small_units_batch_larger_than_the_chip():
+    """More small units than the chip has CUs: the fused tail kernel is launched per (single-/multi-wave, light/heavy LDS)
+    class instead of once, and the row pass takes its per-class launches (more than 4096 token rows): still bit-identical
+    to the batched kernels, unit by unit."""
+    L = _lib()
+    rng = np.random.RandomState(77)
+    shapes = [(64, 0, 250), (74, 100, 400), (130, 0, 60), (30, 0, 1025), (16, 0, 1500)]      # heavy / multi-wave members
+    Ts, Fs = synth.draw_real_shapes(123, 330)
+    for T, F in zip(Ts, Fs):
+        T, F = int(min(T, 60)), int(min(F, 700))
+        F = max(F, T + 1)
+        s = int(rng.randint(0, 1500 - F + 1))
+        shapes.append((T, s, s + F))
+    assert sum(L.small_unit(T, e - s) for T, s, e in shapes) > 256
+    fused = _align_units(shapes, torch.float32, L.WT_ALIGN_KEEP_COST, seed=9000, want_path=False)
+    plain = _align_units(shapes, torch.float32, L.WT_ALIGN_KEEP_COST | L.WT_ALIGN_NO_FUSED_SMALL_UNITS, seed=9000, want_path=False)
+    assert torch.equal(fused["jumps"], plain["jumps"])
+    for d in fused["descs"]:
+        c0, n = int(d["cost_offset"]), int(d["T"]) * int(d["F"])
+        assert torch.equal(fused["cost"][c0:c0 + n], plain["cost"][c0:c0 + n]), (int(d["T"]), int(d["F"]))
+    d = fused["descs"][0]
+    T, F = int(d["T"]), int(d["F"])
+    r = O.dtw_ref(fused["cost"][:T * F].reshape(T, F).cpu().numpy().astype(np.float64))
+    assert np.array_equal(fused["jumps"][:T + 1].cpu().numpy(), O.jumps_from_path(r.index1s, r.index2s))
