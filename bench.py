@@ -1029,6 +1029,9 @@ def orchestrate(args):
     if err:
         out["kernel_leg_error"] = err
     out["kernel_leg_attempts"] = attempts
+    # A recurrence of a GPU fault must not read as a clean pass: whatever the retried number is, the line says at its
+    # top level that an attempt ended on a signal / non-zero exit.
+    out["faulted"] = bool(attempts > 1 or err)
     print("[bench] kernel-level headline: " + json.dumps({k: out.get(k) for k in ("value", "unit", "ms_per_step", "roofline")}),
           file=sys.stderr, flush=True)
     if world == 1 and not args.dry_run:

@@ -31,7 +31,12 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 3 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3 */
+#define WT_ABI_VERSION 4 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3;
+                            4: + wt_release_stream; only the WT_API entries are exported (the library is built with
+                               -fvisibility=hidden) */
+
+/* The exported surface: exactly the functions marked WT_API below (tests/test_host_cpu.py holds `nm -D` to it). */
+#define WT_API __attribute__((visibility("default")))
 
 #define WT_OK 0
 #define WT_E_BADARG (-1)      /* null pointer, negative size, bad dtype ...          */
@@ -70,9 +75,15 @@ typedef struct wt_seg_desc {
                              as a column index RELATIVE to start_token.                      */
 } wt_seg_desc;
 
-int wt_version(void);
-const char *wt_last_error(void);
-int wt_shutdown(void);
+WT_API int wt_version(void);
+WT_API const char *wt_last_error(void);
+WT_API int wt_shutdown(void);
+
+/* Frees the scratch arenas the library keeps for `stream` on every device (the arenas are keyed by (device, purpose,
+ * stream): a process that creates and destroys streams calls this before hipStreamDestroy, otherwise one arena set
+ * per stream stays allocated until wt_shutdown).  The stream's queued work must have completed (the call does not
+ * synchronise it).  Returns the number of arenas freed (>= 0). */
+WT_API int wt_release_stream(void *stream);
 
 /* T.py:783-793 hook_attention_weights.  Copies the LAST query row of n_sel heads of one decoder layer's
  * cross-attention QK logits into the device capture ring (instead of the reference's `w[:, :, -1:, :].cpu()`
@@ -81,7 +92,7 @@ int wt_shutdown(void);
  *   heads    : device int32[n_sel], head index inside this layer
  *   slots    : device int32[n_sel], destination head slot in the ring
  *   ring     : device, [n_slots][ring_rows][n_ctx] of ring_dtype; writes ring[slots[i]][row][:]        */
-int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ctx, const int32_t *heads,
+WT_API int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ctx, const int32_t *heads,
                     const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row,
                     void *stream);
 
@@ -91,7 +102,7 @@ int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ct
  * whisper.model.disable_sdpa(), just to read these rows: T.py:49-61, 903).
  *   q : device [n_rows][d_model]   (cross_attn.query output rows; dtype f32/f16)
  *   k : device [n_ctx][d_model]    (cross_attn.key output of the window)                                       */
-int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int d_model, int head_dim, float scale,
+WT_API int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, int d_model, int head_dim, float scale,
                const int32_t *heads, const int32_t *slots, int n_sel, void *ring, int ring_dtype, int64_t ring_rows,
                int64_t row0, void *stream);
 
@@ -107,7 +118,7 @@ int wt_qk_rows(const void *q, const void *k, int dtype, int n_rows, int n_ctx, i
  *   row_begin/row_end             : device int32[n_batch] or NULL (= all n_q rows)
  *   ring                          : device [n_batch][n_slots][ring_rows][n_ctx] (ring_batch_stride elements per window)
  * head_dim must be 64 (every Whisper checkpoint).  Arithmetic identical to wt_qk_rows. */
-int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,
+WT_API int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,
                      int n_q, int64_t q_batch_stride, int64_t k_batch_stride, int n_ctx, int d_model, int head_dim,
                      float scale, const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
                      const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_batch_stride,
@@ -126,7 +137,7 @@ int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_laye
  *   head_idx  : device int32[n_heads], flat head indices in the order of
  *               alignment_heads.indices().T (T.py:1545); all heads => 0..L*H-1
  *   cost      : device fp32, written at segs[i].cost_offset (T*F each)       */
-int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+WT_API int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                   const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, void *stream);
 
 /* T.py:1572,1581 dtw.dtw(cost, step_pattern=symmetric1) + T.py:1648-1652.
@@ -140,7 +151,7 @@ int wt_cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, co
  *              (alignment.index1s / index2s) at path_offset, forward order
  *   path_len : optional device int32[n_seg]
  *   dist     : optional device double[n_seg] = alignment.distance            */
-int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
+WT_API int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, int32_t *jumps,
                  int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
 
 /* wt_dtw_batch with an explicit step pattern:
@@ -150,12 +161,13 @@ int wt_dtw_batch(const float *cost, const wt_seg_desc *segs_host, const wt_seg_d
  *                               a timestamp; needs T <= F per unit (WT_E_UNSUPPORTED otherwise: dtw-python finds no path) */
 #define WT_STEP_SYMMETRIC1 0
 #define WT_STEP_NO_EMPTY_SUBWORDS 1
-int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+WT_API int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                          int step_pattern, int32_t *jumps, int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist,
                          void *stream);
 
 /* wt_cost_batch followed by wt_dtw_batch on the same stream = perform_word_alignment's numerics (T.py:1540-1581,
- * 1648-1652) for a batch of units.  Units with T <= 64 whose (T, F) matrix fits a workgroup's LDS -- the reference's
+ * 1648-1652) for a batch of units.  Units whose (T, F) matrix, direction planes and boundary rows fit a workgroup's 160 KB of LDS
+ * (any T <= 256; e.g. T = 64 up to F = 480, T = 16 up to F = 1792: csrc/wt_small.h) -- the reference's
  * default per-segment call shape (T.py:544-557: T p50 11, F p50 144) -- leave the batched kernels after the row pass:
  * ONE fused kernel does their column norm, cost[0,0], DTW and backtrack in one workgroup with the matrix in LDS; which
  * path a unit takes depends on its own shape only, and cost / jumps are bit-identical on both.
@@ -169,10 +181,10 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
 #define WT_ALIGN_KEEP_COST 1
 #define WT_ALIGN_NO_FUSED_SMALL_UNITS 2
 #define WT_ALIGN_ROWS_PER_CLASS 4
-int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+WT_API int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                       const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                       int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, int flags, void *stream);
-int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
+WT_API int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                    const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,
                    int32_t *path_i, int32_t *path_j, int32_t *path_len, double *dist, void *stream);
 
@@ -182,13 +194,13 @@ int wt_align_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, c
  *   cost, jumps : what wt_cost_batch / wt_dtw_batch wrote (same descriptors)
  *   jumps_start : device int32, T+1 per unit at jumps_offset: [t] = the (possibly moved) start of token t,
  *                 [T] = jumps[T].  The reference passes width=3, prominence=0.02. */
-int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps,
+WT_API int wt_disfluency_batch(const float *cost, const wt_seg_desc *segs_dev, int n_seg, const int32_t *jumps,
                         int32_t *jumps_start, double min_prominence, double min_width, void *stream);
 
 /* T.py:1795-1805 find_start_padding on a batch of (n_mels, n_cols) log-mel
  * windows: out[b] = None(-1) if the last column is not all-zero, else the
  * index after the last column in [1, n_cols-2] that differs from zero, else 0. */
-int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, void *stream);
+WT_API int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int n_cols, int32_t *out, void *stream);
 
 /* Confidence path: T.py:871-876 (efficient: log_softmax of the filtered
  * logits, gather of the chosen token T.py:735) and T.py:1245,1292 (naive).
@@ -196,13 +208,13 @@ int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mels, int 
  *     out[r] = log_softmax(row with suppressed entries at -inf)[token[r]]
  *   suppress      : optional device uint8[n_rows_or_1][V] (1 = -inf), or NULL
  *   suppress_rows : 0 = none, 1 = one shared mask row, n_rows = per-row masks */
-int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
+WT_API int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
                             const int32_t *token, const uint8_t *suppress, int suppress_rows, float *out, void *stream);
 
 /* The same gather with an explicit row list: out[r] = log_softmax(logits row row_index[r])[token[r]], r < n_out.
  * Rows may repeat or be skipped: T.py:1292 `logprobs[:, step, tok]` for the text positions of many teacher-forced
  * windows at once, read from one padded (n_windows * T_max, V) logits block (no logit filters on this path, T.py:1245). */
-int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_stride, const int32_t *row_index, int n_out,
+WT_API int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_stride, const int32_t *row_index, int n_out,
                            int V, const int32_t *token, float *out, void *stream);
 
 /* openai-whisper audio.log_mel_spectrogram + pad_or_trim as called at
@@ -219,7 +231,7 @@ int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_str
  * n_frames may be anything (a whole file: n_samples / 160); the log10 uses the hardware log2 (|err| < 3e-7) and
  * the power is |X|^2 without the square root round trip of torch's abs()**2: results agree with
  * torch.stft-based log_mel_spectrogram to 2e-4 absolute (tests/test_gpu_parity.py). */
-int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
+WT_API int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
                     int n_mels, int n_frames, float *mel_out, float *gmax, void *stream);
 
 #ifdef __cplusplus

@@ -40,6 +40,7 @@ def test_one_rank_prints_exactly_one_json_line():
     check_line(d, 1)
     assert d["config"]["result_gather"] == "none"
     assert d["kernel_leg_attempts"] == 1
+    assert d["faulted"] is False
 
 
 def test_gpus_2_launches_itself_under_torchrun():
@@ -66,6 +67,7 @@ def test_a_dead_kernel_leg_is_rerun_and_reported():
     d = json.loads(lines[0])
     check_line(d, 1)
     assert d["kernel_leg_attempts"] == 2
+    assert d["faulted"] is True
     assert d["kernel_leg_first_attempt"]["error"] == "signal 6"
 
 

@@ -7,7 +7,9 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "guard", "libwtguard.so")),
+                                 reason="tests/guard/libwtguard.so was not built (__graft_entry__.build() reports why)")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNNER = os.path.join(ROOT, "tests", "guard", "run_guarded.py")

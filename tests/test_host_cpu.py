@@ -25,7 +25,25 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.wt_version.restype = ctypes.c_int
-    assert L.wt_version() == _lib.ABI_VERSION == 3
+    assert L.wt_version() == _lib.ABI_VERSION == 4
+
+
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """-fvisibility=hidden + csrc/wtalign.map: `nm -D` shows the WT_API entries and nothing else of ours (no mangled
+    C++ internals, no kernel handle objects)."""
+    import subprocess
+    from whisper_timestamped import _lib
+    hdr = open(os.path.join(ROOT, "include", "wtalign.h")).read()
+    declared = sorted(set(re.findall(r"WT_API[^;(]*?\b(wt_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.EXPORTS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == declared, sorted(set(defined) ^ set(declared))
+
+
+def test_release_stream_of_an_unknown_stream_frees_nothing():
+    from whisper_timestamped import _lib
+    assert _lib.release_stream(0x1234) == 0
 
 
 def test_seg_desc_layout_matches_header():

@@ -120,6 +120,27 @@ int wt_shutdown(void) {
     return WT_OK;
 }
 
+// Arenas are keyed by (device, purpose, stream): without this a process that keeps creating streams would keep one arena
+// set per stream until wt_shutdown.  The caller guarantees the stream's work has completed.
+int wt_release_stream(void *stream) {
+    std::lock_guard<std::mutex> lk(wt::g_mu);
+    int freed = 0, cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto it = wt::g_arena.begin(); it != wt::g_arena.end();) {
+        if (std::get<2>(it->first) == (hipStream_t)stream) {
+            if (it->second.p) {
+                (void)hipSetDevice(std::get<0>(it->first));
+                (void)hipFree(it->second.p);
+                ++freed;
+            }
+            it = wt::g_arena.erase(it);
+        } else
+            ++it;
+    }
+    (void)hipSetDevice(cur);
+    return freed;
+}
+
 int wt_capture_rows(const void *qk, int qk_dtype, int n_heads, int n_q, int n_ctx, const int32_t *heads, const int32_t *slots,
                     int n_sel, void *ring, int ring_dtype, int64_t ring_rows, int64_t row, void *stream) {
     return wt::capture_rows(qk, qk_dtype, n_heads, n_q, n_ctx, heads, slots, n_sel, ring, ring_dtype, ring_rows, row,
@@ -152,8 +173,8 @@ int wt_dtw_batch_pattern(const float *cost, const wt_seg_desc *segs_host, const 
                          (hipStream_t)stream);
 }
 
-// rowmean for every unit; then the units that qualify (wt_small.h: T <= 64 and the LDS they need; a property of the
-// unit's own shape) take the fused tail kernel -- column norm, cost[0,0], DTW and backtrack in one workgroup -- and the
+// rowmean for every unit; then the units that qualify (wt_small.h: the LDS their matrix, planes and boundary rows need --
+// any T <= 256 whose (T, F) fits 160 KB; a property of the unit's own shape) take the fused tail kernel -- column norm, cost[0,0], DTW and backtrack in one workgroup -- and the
 // others colnorm / fix00 / dtw, which skip the small ones.
 int wt_align_batch_v3(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg,
                       const int32_t *head_idx, int n_heads, int medfilt_width, float qk_scale, float *cost, int32_t *jumps,

@@ -13,13 +13,13 @@
 //   2. columns     one thread per frame: sum of squares over tokens in f64 with colnorm_kernel's summation tree (the
 //                  matrix is BIT-IDENTICAL to the batched kernels'), normalise, negate, pad mask, unit max
 //   3. cost[0,0] = min; optionally the matrix goes back to HBM (callers that keep it: disfluency detection, tests)
-//   4. DTW         wave 0, one lane per token row, the anti-diagonal sweep of wt_dtw_core.h reading 32-frame blocks of
+//   4. DTW         ceil(T/64) waves pipelined through LDS boundary rows, one lane per token row, the anti-diagonal sweep of wt_dtw_core.h reading 32-frame blocks of
 //                  its row from LDS (the matrix is stored SKEWED, row i shifted right by i, so that at step s every
 //                  lane reads column s of its row: 16-byte aligned ds_read_b128), direction planes to LDS
 //   5. backtrack   wt_dtw_core.h, planes from LDS -> jumps[T+1] (+ path, distance)
 // The matrix crosses HBM once in each direction instead of five times, and a batch of small units is TWO launches
-// (rowmean + this) instead of up to nine.  A unit qualifies by its own shape alone (wt_small_unit: T <= 64 and the LDS
-// it needs), so the same unit takes the same path in any batch.
+// (rowmean + this) instead of up to nine.  A unit qualifies by its own shape alone (wt_small_unit: T <= 256 and the 160 KB of LDS
+// its matrix, planes and boundary rows need), so the same unit takes the same path in any batch.
 #include <algorithm>
 #include <mutex>
 
@@ -246,7 +246,10 @@ static int launch_tail(bool multi, const wt_seg_desc *segs_dev, int unit0, int n
 
 // A launch lasts as long as its longest DTW chain, so splitting a batch adds chains up: a batch with no more small units
 // than the chip has CUs is ONE launch over the range of its small units (largest LDS appetite and, when a unit of more
-// than 64 rows is among them, the multi-wave instantiation for all).  A larger batch is split by what limits how many
+// than 64 rows is among them, the multi-wave instantiation for all).  With <= 256 workgroups every unit has a CU of its
+// own whatever LDS the launch reserves, so the shared sizing costs nothing in occupancy; what the light units pay in a
+// mixed launch is the multi-wave body's per-step overhead (progress-word test), which is why RESULTS never depend on the
+// batch but a light unit's share of the launch time can (accepted, documented).  A larger batch is split by what limits how many
 // workgroups share a CU: single-wave units apart from multi-wave ones (registers), "light" units (<= WT_SMALL_LIGHT_LDS)
 // apart from heavy ones (LDS).
 int align_small_tail(const wt_seg_desc *segs_host, const wt_seg_desc *segs_dev, int n_seg, float *cost, bool keep_cost,

@@ -30,9 +30,10 @@ assert SEG_DTYPE.itemsize == 64
 
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
-           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3"]
+           "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3",
+           "wt_release_stream"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS, WT_ALIGN_ROWS_PER_CLASS = 1, 2, 4
 
 
@@ -70,6 +71,7 @@ def load():
                                    i64, i64, vp]
     L.wt_logprob_gather_rows.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp]
     L.wt_dtw_batch_pattern.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.wt_release_stream.argtypes = [vp]
     if L.wt_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} exports ABI version {L.wt_version()}, this package needs {ABI_VERSION}: rebuild it "
                           f"(`make -C {_PKG_ROOT}/csrc`)")
@@ -83,6 +85,16 @@ def _check(rc: int, what: str):
     if rc != 0:
         msg = load().wt_last_error().decode("utf-8", "replace")
         raise WtError(f"{what} failed (rc={rc}): {msg}")
+
+
+def release_stream(stream) -> int:
+    """Free the scratch arenas the library keeps for a HIP stream (a ``torch.cuda.Stream`` or a raw handle) whose work
+    has completed: call it before dropping a stream the kernels were launched on.  Returns the number of arenas freed."""
+    handle = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+    rc = load().wt_release_stream(handle)
+    if rc < 0:
+        _check(rc, "wt_release_stream")
+    return rc
 
 
 def _stream(device=None) -> int:

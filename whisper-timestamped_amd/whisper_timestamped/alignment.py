@@ -283,7 +283,15 @@ class AlignmentBatch:
         try:
             self._launch_on(slot, ws, units, order, dev, dt, esz, base)
         except BaseException:
-            ws.release(slot)          # (a refused batch -- WT_E_UNSUPPORTED ... -- must not cost the pool a slot)
+            # A refused batch (WT_E_UNSUPPORTED ...) must not cost the pool a slot -- but an entry point may have queued
+            # kernels on this slot's buffers before a LATER one refused (align ok, disfluency refused): the slot only
+            # goes back once the stream has drained, so nobody else can be handed buffers that are still being written.
+            try:
+                torch.cuda.current_stream(dev).synchronize()
+            except Exception:      # (a dead device: drop the slot instead of pooling it)
+                raise
+            else:
+                ws.release(slot)
             raise
         return self
 

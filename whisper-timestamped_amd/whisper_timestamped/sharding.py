@@ -212,7 +212,8 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
 # with its own copy of the model (whisper-base: 290 MB of 288 GB) and its own HIP queues, fill the GPU the way W batch
 # streams would, with no change to the backend's loop and therefore to its output.  No collective anywhere: a job queue
 # in, result dictionaries out.
-def _many_worker(rank, n_workers, devices, load_model, audios, order, options, barrier, out_queue, on_item, warmup):
+def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options, barrier, out_queue, on_item, warmup):
+    """`mine` = the indices (into the caller's list) of this worker's recordings, `my_audios` = those recordings only."""
     import time
     import os
     # W processes with the default intra-op thread count each (= every core of the host) fight for cores (the CPU test of
@@ -225,21 +226,20 @@ def _many_worker(rank, n_workers, devices, load_model, audios, order, options, b
         torch.cuda.set_device(dev)
     from .transcribe import transcribe_timestamped
     model = load_model(dev)
-    mine = order[rank]
     if warmup and mine:                          # allocations, GEMM plans, the library's arenas: before the common start
         if on_item is not None:
             on_item(mine[0])
-        transcribe_timestamped(model, audios[mine[0]], **options)
+        transcribe_timestamped(model, my_audios[0], **options)
     if on_gpu:
         torch.cuda.synchronize(dev)
     if barrier is not None:
-        barrier.wait()
+        barrier.wait(timeout=600)                # (BrokenBarrierError when the parent aborted it: a sibling died)
     t0 = time.perf_counter()
     res = []
-    for i in mine:
+    for i, audio in zip(mine, my_audios):
         if on_item is not None:
             on_item(i)
-        res.append((i, transcribe_timestamped(model, audios[i], **options)))
+        res.append((i, transcribe_timestamped(model, audio, **options)))
     if on_gpu:
         torch.cuda.synchronize(dev)
     out_queue.put((rank, time.perf_counter() - t0, res))
@@ -263,8 +263,9 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     ctx = mp.get_context("spawn")
     barrier = ctx.Barrier(n_workers)
     queue = ctx.Queue()
-    procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, audios, order, options, barrier, queue,
-                                                    on_item, warmup)) for r in range(n_workers)]
+    # every worker is sent ITS recordings only (spawn pickles the arguments: W x the whole list otherwise)
+    procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, [audios[i] for i in order[r]], order[r],
+                                                    options, barrier, queue, on_item, warmup)) for r in range(n_workers)]
     for p in procs:
         p.daemon = True           # (a worker never outlives the process that asked for it)
         p.start()
@@ -281,9 +282,17 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
                         raise RuntimeError(f"transcribe_many: a worker died (exit code {dead[0].exitcode})")
             slowest = max(slowest, seconds)
             got.update(dict(res))
+    except BaseException:
+        # a worker that died before the barrier would leave its siblings waiting there for good: break the barrier and
+        # stop everybody at once instead of joining blocked workers one by one
+        barrier.abort()
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        raise
     finally:
         for p in procs:
-            p.join(timeout=30)
+            p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
     assert sorted(got) == list(range(len(audios)))
