@@ -463,6 +463,7 @@ def e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm, window_tokens)
         lp = [logprobs[:, step, tok] for step, tok in zip(range(i_start, i_start + len(ids)), ids)]
         i_start += len(word["tokens"])
         word["confidence_raw"] = torch.cat(lp).mean().exp().item() if lp else 0.0
+        word["mean_logprob_raw"] = torch.cat(lp).mean().item() if lp else None
     return ws
 
 
@@ -529,7 +530,7 @@ def run_e2e(dev, args, leg, emit):
             # the same chunks through the reference-shaped CPU path, bounded sample
             model_cpu = W.build_model(name, seed=0, device="cpu")
             pcm_cpu = pcm[:8].cpu()
-            done, worst_t, worst_c, t0 = 0, 0.0, 0.0, time.perf_counter()
+            done, worst_t, worst_c, worst_l, t0 = 0, 0.0, 0.0, 0.0, time.perf_counter()
             while done < 8:
                 ws = e2e_cpu_reference_window(W, model_cpu, tokenizer, heads, pcm_cpu[done], transcripts[done])
                 got = res32[done]
@@ -538,6 +539,11 @@ def run_e2e(dev, args, leg, emit):
                     worst_t = max(worst_t, abs(a["start"] - b["start"]), abs(a["end"] - b["end"]))
                     conf = lp.mean().exp().item() if len(lp) else 0.0
                     worst_c = max(worst_c, abs(conf - b["confidence_raw"]))
+                    # (a random-init model gives p ~ 1/V: the confidences are ~1e-8 and their difference says nothing;
+                    #  the mean log-probabilities they are the exp() of are compared as well)
+                    assert (len(lp) == 0) == (b["mean_logprob_raw"] is None)
+                    if len(lp):
+                        worst_l = max(worst_l, abs(lp.mean().item() - b["mean_logprob_raw"]))
                 done += 1
                 if time.perf_counter() - t0 > args.e2e_cpu_budget:
                     break
@@ -548,7 +554,10 @@ def run_e2e(dev, args, leg, emit):
                                                  f"the same whisper-base on the CPU with unfused attention and per-layer QK capture, "
                                                  f"log_softmax of the (T, V) block, oracle perform_word_alignment, {el:.1f} s wall"}
             out["parity_vs_cpu_reference_path"] = {"chunks": done, "max_abs_dt_word_s": round(worst_t, 4),
-                                                   "max_abs_dconfidence_before_rounding": float(f"{worst_c:.3g}")}
+                                                   "max_abs_dconfidence_before_rounding": float(f"{worst_c:.3g}"),
+                                                   "max_abs_dmean_logprob_per_word": float(f"{worst_l:.3g}"),
+                                                   "bars": {"dt_word_s": 0.02, "dconfidence": 1e-4, "dmean_logprob": 2e-4}}
+            assert worst_t <= 0.02 + 1e-9 and worst_c <= 1e-4 and worst_l <= 2e-4, out["parity_vs_cpu_reference_path"]
             out["speedup_vs_cpu_e2e"] = round(out["audio_s_per_s"] / out["cpu_baseline_e2e"]["value"], 1)
             emit(out)
         return out

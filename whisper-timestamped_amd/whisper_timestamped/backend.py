@@ -43,7 +43,17 @@ def attention_weights_exposed(enabled=True):
 
 
 def get_tokenizer(model, task="transcribe", language="en"):
-    """transcribe.py:1406-1426 (openai-whisper branch)."""
+    """transcribe.py:1406-1426 (openai-whisper branch).  With ``model.tokenizer_vocab`` (a path) or $WT_TOKENIZER_VOCAB
+    set, the vocabulary comes from that ``.tiktoken`` file through this package's own loader (vocab.py: no
+    ``tiktoken`` extension needed) instead of the backend's."""
+    import os
+    vocab = getattr(model, "tokenizer_vocab", None) or os.environ.get("WT_TOKENIZER_VOCAB")
+    if vocab:
+        from . import vocab as own
+        if os.path.isdir(vocab):
+            vocab = os.path.join(vocab, "multilingual.tiktoken" if model.is_multilingual else "gpt2.tiktoken")
+        return own.get_tokenizer(model.is_multilingual, num_languages=getattr(model, "num_languages", 99), task=task,
+                                 language=language, vocab_path=vocab)
     tk = whisper().tokenizer
     try:
         return tk.get_tokenizer(model.is_multilingual, num_languages=getattr(model, "num_languages", 99), task=task,
