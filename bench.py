@@ -83,6 +83,20 @@ def result_buffers(n_jumps, n_logprob, dev):
                 host_jumps=host[:n_jumps], host_logprob=host[n_jumps:].view(torch.float32))
 
 
+PADDED_EVERY = 16          # SURVEY.md 8(d) set K: "pad_from = -1 except 1/16 of segments with pad_from = U[F/2, F)"
+
+
+def padded_chunks(n, F, rs):
+    """Which chunks end in silence, and from which 20 ms frame on: chunk b (b % 16 == 7) holds only pad_from * 320 real
+    samples -- its log-mel is exact zeros from column 2 * pad_from (pad_or_trim), find_start_padding returns that
+    column, and T.py:1554-1565 masks the cost matrix from frame pad_from = column // 2."""
+    pad = np.full(n, -1, dtype=np.int64)
+    for b in range(n):
+        if b % PADDED_EVERY == PADDED_EVERY // 2 - 1:
+            pad[b] = int(rs.randint(F // 2, F))
+    return pad
+
+
 def make_workload(dev, cfg, seed):
     from whisper_timestamped import _lib
     if cfg.get("units_per_chunk"):
@@ -93,25 +107,34 @@ def make_workload(dev, cfg, seed):
     qk_half = cfg.get("qk_dtype") == "f16"
     # monotone ridge (+6 on a token->frame staircase, 3 frames wide): SURVEY.md 8(d) set K
     rs = np.random.RandomState(seed)
-    stairs = np.sort(rs.randint(0, F, size=(n, T)), axis=1)
+    pad = padded_chunks(n, F, rs)
+    stairs = np.stack([np.sort(rs.randint(0, F if pad[b] < 0 else pad[b], size=T)) for b in range(n)])
     st = torch.from_numpy(stairs).to(dev)
     fr = torch.arange(1500, device=dev).view(1, 1, 1500)
     ridge = ((fr - st.unsqueeze(-1)).abs() <= 1).to(torch.float32) * 6.0
     qk += ridge.unsqueeze(1)
     del ridge
+    sample = parity_sample_units(pad)
+    qk_f32_sample = {b: qk[b].cpu() for b in sample} if qk_half else None     # (what the fp16 rows were rounded from)
     if qk_half:
         qk = qk.half()
     logits = torch.randn((n * T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
     tokens = torch.randint(0, V, (n * T,), generator=g, device=dev, dtype=torch.int32)
     pcm = torch.randn((n, 480000), generator=g, device=dev, dtype=torch.float32) * 0.1
+    n_valid = np.where(pad >= 0, pad * 320, 480000).astype(np.int32)
+    for b in np.nonzero(pad >= 0)[0]:
+        pcm[b, int(n_valid[b]):] = 0.0
     from whisper_timestamped.audio import mel_filters
     fb = mel_filters(dev, cfg["n_mels"])
     descs = _lib.make_descs(n)
     for b, d in enumerate(descs):
         d["qk_offset"], d["head_stride"], d["row_stride"] = b * A * T * 1500, T * 1500, 1500
-        d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, 0, -1
+        d["T"], d["F"], d["start_token"], d["pad_from"] = T, F, 0, int(pad[b])
     n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
+    cfg = dict(cfg, pad_from=[int(x) for x in pad], n_valid=[int(x) for x in n_valid])
     w = dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=fb, descs=descs,
+             n_valid=torch.from_numpy(n_valid).to(dev), parity_units=sample, qk_f32_sample=qk_f32_sample,
+             unit_chunk=list(range(n)), unit_row0=[0] * n, unit_logit_row0=[b * T for b in range(n)],
              descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
              cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
              **result_buffers(n_jumps, n * T, dev),
@@ -120,6 +143,66 @@ def make_workload(dev, cfg, seed):
              pad=torch.empty(n, dtype=torch.int32, device=dev),
              stairs=stairs)
     return w
+
+
+def parity_sample_units(pad):
+    """The units the in-leg parity check compares with the oracle: the first one, and the first padded one."""
+    padded = [int(b) for b in np.nonzero(pad >= 0)[0][:1]]
+    return sorted(set([0] + padded))
+
+
+def parity_in_leg(w):
+    """A few units of the batch the timed region has just processed, through the oracle (oracle/: the CPU restatement of
+    the reference; used here as the CHECKER, never as the thing measured): the jumps of the last timed step must be the
+    oracle's for the same logits -- bit for bit with fp32 rows; with fp16 rows (a storage option the reference does not
+    have) against the oracle on the same rounded logits AND on the fp32 logits they were rounded from (max |d frame|) --
+    the log-probabilities within 2e-5, the padding index exact, the log-mel within 2e-4."""
+    from oracle import align_ref as O
+    cfg = w["cfg"]
+    A, V = cfg["A"], cfg["V"]
+    torch.cuda.synchronize()
+    hj, hl = w["host_jumps"].numpy(), w["host_logprob"].numpy()
+    pad_dev = w["pad"].cpu().numpy()
+    out = {"units": [], "jumps_equal_oracle": True, "max_abs_dlogprob": 0.0, "padding_index_equal_oracle": True}
+    qk = w["qk"]
+    rows = qk.shape[2]
+    worst_half = 0
+    for k in w["parity_units"]:
+        d = w["descs"][k]
+        T, F, start, pf = int(d["T"]), int(d["F"]), int(d["start_token"]), int(d["pad_from"])
+        b, r0 = w["unit_chunk"][k], w["unit_row0"][k]
+        sel = qk[b, :, r0:r0 + T, start:start + F].float().cpu()
+        cost = O.cost_matrix_ref(sel, 9, 1.0, pf if pf > 0 else None, start)
+        r = O.dtw_ref(cost)
+        want = O.jumps_from_path(r.index1s, r.index2s)
+        j0 = int(d["jumps_offset"])
+        got = hj[j0:j0 + T + 1]
+        same = bool(np.array_equal(got, want))
+        out["jumps_equal_oracle"] &= same
+        rec = {"unit": int(k), "T": T, "F": F, "pad_from": pf, "jumps_equal": same}
+        if w.get("qk_f32_sample") is not None:
+            sel32 = w["qk_f32_sample"][b][:, r0:r0 + T, start:start + F]
+            r32 = O.dtw_ref(O.cost_matrix_ref(sel32, 9, 1.0, pf if pf > 0 else None, start))
+            df = int(np.abs(O.jumps_from_path(r32.index1s, r32.index2s) - got).max())
+            rec["max_dframe_vs_fp32_oracle_on_the_fp32_logits"] = df
+            worst_half = max(worst_half, df)
+        l0 = w["unit_logit_row0"][k]
+        ref = O.token_logprob_gather_ref(w["logits"][l0:l0 + T].cpu(), w["tokens"][l0:l0 + T].cpu().numpy()).numpy()
+        out["max_abs_dlogprob"] = max(out["max_abs_dlogprob"], float(np.abs(ref - hl[l0:l0 + T]).max()))
+        nv = int(cfg["n_valid"][b])
+        mel_ref = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(w["pcm"][b, :nv].cpu(), cfg["n_mels"]), 3000)
+        rec["max_abs_dlogmel"] = float((w["mel"][b].cpu() - mel_ref).abs().max())
+        sp = O.find_start_padding_ref(mel_ref[None])
+        out["padding_index_equal_oracle"] &= (int(pad_dev[b]) == (-1 if sp is None else int(sp)))
+        out["units"].append(rec)
+    out["max_abs_dlogprob"] = float(f"{out['max_abs_dlogprob']:.3g}")
+    out["max_abs_dlogmel"] = float(f"{max(u['max_abs_dlogmel'] for u in out['units']):.3g}")
+    if w.get("qk_f32_sample") is not None:
+        out["fp16_rows_max_dframe_vs_fp32_oracle"] = worst_half
+    ok = out["jumps_equal_oracle"] and out["padding_index_equal_oracle"] and out["max_abs_dlogprob"] <= 2e-5 and \
+        out["max_abs_dlogmel"] <= 2e-4
+    out["ok"] = bool(ok)
+    return out
 
 
 def make_workload_kreal(dev, cfg, seed):
@@ -134,6 +217,7 @@ def make_workload_kreal(dev, cfg, seed):
     rows_per_chunk = 256
     qk = torch.randn((n, A, rows_per_chunk, 1500), generator=g, device=dev, dtype=torch.float32)
     rs = np.random.RandomState(seed)
+    pad = padded_chunks(n, 1500, rs)           # the chunk's mel is zero from column 2 * pad[b]: max_duration = pad[b]
     raw, tot_T = [], 0
     for b in range(n):
         row = 0
@@ -143,11 +227,15 @@ def make_workload_kreal(dev, cfg, seed):
             T = max(T, 2)
             F = max(F, T + 1)
             start = int(rs.randint(0, 1500 - F + 1))
-            st = np.sort(rs.randint(0, F, size=T))
+            # T.py:1561-1565: the mask applies when the window starts before max_duration, and is then applied at the
+            # ABSOLUTE index used as a relative column (the reference's quirk): columns >= pad[b] of the window
+            pf = int(pad[b]) if (pad[b] >= 0 and start < pad[b]) else -1
+            st = np.sort(rs.randint(0, F if (pf < 0 or pf >= F) else max(pf, 1), size=T))
             for t in range(T):
                 a, e = start + max(st[t] - 1, 0), start + min(st[t] + 2, F)
                 qk[b, :, row + t, a:e] += 6.0
-            raw.append(dict(qk_offset=(b * A * rows_per_chunk + row) * 1500, T=T, F=F, start=start, stairs=st))
+            raw.append(dict(qk_offset=(b * A * rows_per_chunk + row) * 1500, T=T, F=F, start=start, stairs=st, pad_from=pf,
+                            chunk=b, row0=row, logit_row0=tot_T))
             row += T
             tot_T += T
     order = _lib.launch_order([(r["T"], r["F"]) for r in raw])      # grouped by F class, as AlignmentBatch does
@@ -156,14 +244,23 @@ def make_workload_kreal(dev, cfg, seed):
     for d, i in zip(descs, order):
         r = raw[i]
         d["qk_offset"], d["head_stride"], d["row_stride"] = r["qk_offset"], rows_per_chunk * 1500, 1500
-        d["T"], d["F"], d["start_token"], d["pad_from"] = r["T"], r["F"], r["start"], -1
+        d["T"], d["F"], d["start_token"], d["pad_from"] = r["T"], r["F"], r["start"], r["pad_from"]
         stairs.append(r["stairs"])
+    n_valid = np.where(pad >= 0, pad * 320, 480000).astype(np.int32)
+    masked = [k for k, i in enumerate(order) if 0 < raw[i]["pad_from"] < raw[i]["F"]]
+    sample = sorted(set([0, len(order) // 2] + masked[:1]))
     n_cost, n_jumps, n_path = _lib.layout_outputs(descs)
     logits = torch.randn((tot_T, V), generator=g, device=dev, dtype=torch.float32) * 3.0
     tokens = torch.randint(0, V, (tot_T,), generator=g, device=dev, dtype=torch.int32)
     pcm = torch.randn((n, 480000), generator=g, device=dev, dtype=torch.float32) * 0.1
-    cfg = dict(cfg, n_rows=tot_T, units=[(int(d["T"]), int(d["F"])) for d in descs])
+    for b in np.nonzero(pad >= 0)[0]:
+        pcm[b, int(n_valid[b]):] = 0.0
+    cfg = dict(cfg, n_rows=tot_T, units=[(int(d["T"]), int(d["F"])) for d in descs], pad_from=[int(x) for x in pad],
+               n_valid=[int(x) for x in n_valid])
     return dict(cfg=cfg, qk=qk, logits=logits, tokens=tokens, pcm=pcm, fb=mel_filters(dev, cfg["n_mels"]), descs=descs,
+                n_valid=torch.from_numpy(n_valid).to(dev), parity_units=sample, qk_f32_sample=None,
+                unit_chunk=[raw[i]["chunk"] for i in order], unit_row0=[raw[i]["row0"] for i in order],
+                unit_logit_row0=[raw[i]["logit_row0"] for i in order],
                 descs_dev=_lib.descs_to_device(descs, dev), head_idx=torch.arange(A, dtype=torch.int32, device=dev),
                 cost=torch.empty(n_cost, dtype=torch.float32, device=dev),
                 **result_buffers(n_jumps, tot_T, dev),
@@ -209,7 +306,7 @@ def _stage_calls(w):
     n_rows = cfg.get("n_rows") or n * cfg["T"]
 
     def logmel(st):
-        _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, 0, w["fb"].data_ptr(), cfg["n_mels"], 3000,
+        _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, w["n_valid"].data_ptr(), w["fb"].data_ptr(), cfg["n_mels"], 3000,
                                       w["mel"].data_ptr(), w["gmax"].data_ptr(), st), "wt_logmel_batch")
 
     def padding(st):
@@ -351,12 +448,16 @@ def algorithmic_bytes(cfg, fused=False):
     s_in = 2 if cfg.get("qk_dtype") == "f16" else 4
     tf = sum(t * f for t, f in units)
     rows = sum(t for t, _ in units)
+    n_valid = cfg.get("n_valid") or [480000] * n
+    logmel = sum(v * 4 for v in n_valid) + n * M * 3000 * 4        # the real samples in, the whole (M, 3000) window out
+    # an unpadded window is decided by its last column; a padded one by its zero columns and the first non-zero one
+    padding = sum(M * 4 * (1 if v >= 480000 else (3000 - v // 160 + 1)) for v in n_valid)
     if fused:   # the same bytes as the two stages below, moved by one entry point and timed as one stage
-        return {"logmel": n * (480000 * 4 + M * 3000 * 4), "padding": n * M * 4,
+        return {"logmel": logmel, "padding": padding,
                 "cost": A * tf * s_in + 2 * tf * 4 + 4 * (rows + len(units)), "dtw": 0, "logprob": rows * (V * 4 + 8)}
     return {
-        "logmel": n * (480000 * 4 + M * 3000 * 4),
-        "padding": n * M * 4,                               # an unpadded window is decided by its last column
+        "logmel": logmel,
+        "padding": padding,
         "cost": A * tf * s_in + tf * 4,                    # selected-head logits once, cost once
         "dtw": tf * 4 + 4 * (rows + len(units)),           # read cost once, write jumps
         "logprob": rows * (V * 4 + 8),                     # read each logit row once
@@ -388,9 +489,8 @@ def cpu_baseline(cfg, w, budget_s=12.0, threads=None, distinct=32):
         done, t0 = 0, time.perf_counter()
         while True:
             b = done % nd
-            mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b], cfg["n_mels"]), 3000)
-            O.find_start_padding_ref(mel[None])
-            cost = O.cost_matrix_ref(qk[b][:, :, :cfg["F"]], 9, 1.0, None, 0)
+            mel = O.pad_or_trim_ref(O.log_mel_spectrogram_ref(pcm[b][:cfg["n_valid"][b]], cfg["n_mels"]), 3000)
+            cost = O.cost_matrix_ref(qk[b][:, :, :cfg["F"]], 9, 1.0, O.max_duration_ref(mel[None]), 0)
             r = O.dtw_ref(cost)
             O.jumps_from_path(r.index1s, r.index2s)
             O.token_logprob_gather_ref(logits[b * T:(b + 1) * T], tokens[b * T:(b + 1) * T])
@@ -595,6 +695,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", default="auto", choices=["auto", "on", "off"],
                     help="transcribe()-level legs (whisper-base, batched.py); auto = with the default workload at N=1")
+    ap.add_argument("--other-configs", default="on", choices=["on", "off"],
+                    help="N=1, default workload: also run the kreal / kfull256 / largev3_fp16 kernel-level legs (other_configs)")
     ap.add_argument("--e2e-steps", type=int, default=6, help="launch sets of 32 chunks in the e2e timed region")
     ap.add_argument("--e2e-model", default="base", help="shapes of the e2e leg's model (whisper_double names: base = the "
                                                          "BASELINE config; small, medium, large-v3 ... for other shapes)")
@@ -624,6 +726,7 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-workers", type=int, default=2,
                     help="worker processes per GPU of the default-strategy leg (sharding.transcribe_many)")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--secondary", action="store_true", help=argparse.SUPPRESS)     # a kernel leg of another BASELINE config
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (gloo on the CPU, no kernels, meaningless numbers): what "
                          "tests/test_bench_launcher.py runs where there is no GPU")
@@ -717,21 +820,24 @@ def role_kernel(args):
             pipe.append(c)
         pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
 
+    rank_seconds = []            # N > 1: per timed region, every rank's own seconds (before the closing barrier)
+    use_gather = [True]          # (switched off for the "what does the gather cost" regions at the end)
+
     def full_step(ev=None, k=0, pipelined=False):
         if dry:
             time.sleep(2e-4)
-            if gatherers is not None:
+            if gatherers is not None and use_gather[0]:
                 gatherers[k % args.pipeline if pipelined else 0].gather(w["jumps"], w["logprob"])
             return
         if pipelined:
             j = k % args.pipeline
             with torch.cuda.stream(pipe_streams[j]):
                 run_step(pipe[j], ev, None)
-                if gatherers is not None:
+                if gatherers is not None and use_gather[0]:
                     gatherers[j].gather(pipe[j]["jumps"], pipe[j]["logprob"])
             return
         run_step(w, ev, streams)
-        if gather_buf is not None:
+        if gather_buf is not None and use_gather[0]:
             gather_buf.gather(w["jumps"], w["logprob"])
 
     for k in range(args.warmup):
@@ -802,10 +908,16 @@ def role_kernel(args):
             for g_ in (gatherers if pipelined else gatherers[:1]):
                 g_.drain()
         sync()
+        t_done = time.perf_counter()
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
         if dist is not None:
+            # every rank's own region time (its last kernel / last gather done -> before the closing barrier), then MAX
+            mine = torch.tensor([t_done - t0], dtype=torch.float64, device=dev)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            rank_seconds.append([float(x.item()) for x in every])
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
@@ -848,6 +960,8 @@ def role_kernel(args):
         assert np.median(np.concatenate(devs)) <= 3
         assert np.isfinite(w["host_logprob"].numpy()).all()
 
+    extras = {}                  # parity_in_leg, per_rank, result_gather_share: filled in as they are measured
+
     def line(regions, single_regions, batches_in_flight):
         elapsed = float(np.median(regions))
         stage_ms = {s: float(np.median(stage_samples[s])) for s in STAGES}
@@ -865,7 +979,10 @@ def role_kernel(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not dry else "DRY RUN: no kernels ran, the numbers mean nothing",
-            "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "stages": STAGES,
+            "config": {"workload": cfg["desc"], "units_per_step_per_gpu": n, "units_per_step": len(w["descs"]) if not dry else n,
+                       "padded_units": f"1 chunk in {PADDED_EVERY} ends in silence (pad_from = U[F/2, F), its PCM zero from there): the "
+                                       "padding detector and the pad mask run inside the timed region",
+                       "stages": STAGES,
                        "arithmetic": "f32 cost / log-softmax / log-mel (as the reference's torch CPU ops), f64 DTW (as dtw-python)",
                        "dtw_oracle": "published dtw-python algorithm (symmetric1, strict-< tie order), unpinned against the "
                                      "package itself: absent from the image (tests/test_oracle.py pins it on exhaustive "
@@ -890,14 +1007,34 @@ def role_kernel(args):
                          "traffic_source": traffic_src, "algorithmic_bytes": ab[dom],
                          "achievable_copy_GBps_guide": 6290.0, "achievable_read_GBps_probe": 6600.0},
             "stages": stages,
+            **extras,
         }
 
     single_regions = measure(False)                  # one batch in flight: also the per-stage times and the roofline
     check_results(pipe[:1])
+    if not dry:
+        # a few units of what the timed region has just computed, against the oracle (every rank checks its own batch)
+        extras["parity_in_leg"] = parity_in_leg(w)
+        assert extras["parity_in_leg"]["ok"], extras["parity_in_leg"]
     if rank == 0:
         emit(line(single_regions, single_regions, 1))     # published before the multi-stream pass starts
+    mark = len(rank_seconds)
     regions = measure(True) if args.pipeline > 1 else single_regions
     check_results(pipe)
+    if dist is not None and world > 1:
+        # N > 1: what every rank needed for the same region (a bad scaling curve can be read: one slow GPU, or all of
+        # them waiting), and what the result gather to rank 0 costs (the same regions once more without it)
+        per = np.median(np.asarray(rank_seconds[mark:] if args.pipeline > 1 else rank_seconds), axis=0) / args.steps * 1e3
+        extras["per_rank"] = {"ms_per_step": [round(float(x), 4) for x in per], "min": round(float(per.min()), 4),
+                              "max": round(float(per.max()), 4), "skew_max_over_min": round(float(per.max() / per.min()), 4),
+                              "note": "each rank's own time from the opening barrier to its last kernel / gather done, "
+                                      "median over the timed regions; the headline is the max over ranks incl. the closing barrier"}
+        if gatherers is not None:
+            use_gather[0] = False
+            bare = [timed_region(args.pipeline > 1) for _ in range(5)]
+            use_gather[0] = True
+            extras["result_gather"] = {"ms_per_step_without_gather": round(float(np.median(bare)) / args.steps * 1e3, 4),
+                                       "share_of_step": round(max(0.0, 1.0 - float(np.median(bare)) / float(np.median(regions))), 4)}
     if rank == 0:
         emit(line(regions, single_regions, args.pipeline))
     if dist is not None:
@@ -1032,6 +1169,8 @@ def orchestrate(args):
         out["kernel_leg_first_attempt"] = first
     if rank != 0:
         sys.exit(1 if err else 0)
+    if world > 1 and out is not None:
+        out["cpu_baseline"] = "N=1 line only"
     if out is None:
         out = {"metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks", "value": None, "unit": "audio-seconds/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
@@ -1043,6 +1182,24 @@ def orchestrate(args):
     out["faulted"] = bool(attempts > 1 or err)
     print("[bench] kernel-level headline: " + json.dumps({k: out.get(k) for k in ("value", "unit", "ms_per_step", "roofline")}),
           file=sys.stderr, flush=True)
+    if world == 1 and not args.dry_run and args.workload == "kfull" and args.other_configs == "on":
+        # the other single-GPU BASELINE configurations, each as its own kernel-level leg (same child role, same timed
+        # region, its own in-leg parity check): kreal = the reference's default per-segment call shape, kfull256 /
+        # largev3_fp16 = BASELINE configs[4] shapes at N = 1 (256 chunks; large-v3 heads / mels / vocabulary, fp16 rows)
+        others = {}
+        for wl in ("kreal", "kfull256", "largev3_fp16"):
+            leg, lerr = run_child("kernel", ["--workload", wl, "--min-seconds", "0.5", "--secondary"], 240)
+            leg = leg or {}
+            keep = {k: leg.get(k) for k in ("value", "unit", "ms_per_step", "timing", "single_batch_in_flight", "roofline",
+                                            "stages", "parity_in_leg") if k in leg}
+            if "config" in leg:
+                keep["workload"] = leg["config"]["workload"]
+                keep["alignment_entry"] = leg["config"]["alignment_entry"]
+                keep["units_per_step"] = leg["config"].get("units_per_step")
+            if lerr:
+                keep["error"] = lerr
+            others[wl] = keep
+        out["other_configs"] = others
     if world == 1 and not args.dry_run:
         fixed_shape = not WORKLOADS[args.workload].get("units_per_chunk")
         if not args.no_cpu_baseline and fixed_shape:       # rank 0 at N=1 only (fixed-shape workloads)

@@ -30,6 +30,13 @@ def check_line(d, n):
     assert d["config"]["rccl_ranks_seen"] == n
     assert d["scaling"] == "weak" and d["value"] > 0
     assert "dtw_oracle" in d["config"] and "unpinned" in d["config"]["dtw_oracle"]
+    if n > 1:
+        # a scaling curve that can be read: every rank's own time, their skew, what the result gather costs
+        assert len(d["per_rank"]["ms_per_step"]) == n and d["per_rank"]["min"] <= d["per_rank"]["max"]
+        assert d["per_rank"]["skew_max_over_min"] >= 1.0
+        assert 0.0 <= d["result_gather"]["share_of_step"] < 1.0 and d["result_gather"]["ms_per_step_without_gather"] > 0
+        assert d["cpu_baseline"] == "N=1 line only"
+        assert "roofline" in d and d["roofline"]["bound"] == "hbm"
 
 
 def test_one_rank_prints_exactly_one_json_line():
