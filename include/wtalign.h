@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define WT_ABI_VERSION 4 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3;
-                            4: + wt_release_stream; only the WT_API entries are exported (the library is built with
+                            4: + wt_release_stream, wt_qk_rows_streams; only the WT_API entries are exported (the library is built with
                                -fvisibility=hidden) */
 
 /* The exported surface: exactly the functions marked WT_API below (tests/test_host_cpu.py holds `nm -D` to it). */
@@ -123,6 +123,18 @@ WT_API int wt_qk_rows_batch(const void *const *q_layers_host, const void *const 
                      float scale, const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
                      const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_batch_stride,
                      int64_t ring_rows, int64_t ring_row0, void *stream);
+
+/* wt_qk_rows_batch for B decoder STREAMS stepping together (the efficient strategy, T.py:783-793, with B independent
+ * recordings in one decoder call instead of the reference's batch of one, T.py:806): every stream owns one block of a
+ * (n_streams, n_slots, ring_rows, n_ctx) ring for its whole life, and the streams that take part in a given decoder
+ * call are any subset of them: batch entry b writes ring block ring_index[b] (device int32[n_batch], required).
+ * All n_q query rows are written at ring rows ring_row0 ... (the decode loop passes the last row only: n_q = 1 with
+ * the layer pointers advanced to it).  Arithmetic identical to wt_qk_rows. */
+WT_API int wt_qk_rows_streams(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype,
+                              int n_batch, int n_q, int64_t q_batch_stride, int64_t k_batch_stride, int n_ctx, int d_model,
+                              int head_dim, float scale, const int32_t *sel_layer, const int32_t *sel_head,
+                              const int32_t *sel_slot, int n_sel, const int32_t *ring_index, void *ring, int ring_dtype,
+                              int64_t ring_batch_stride, int64_t ring_rows, int64_t ring_row0, void *stream);
 
 /* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
  * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,

@@ -87,8 +87,8 @@ int align_small_tail(const wt_seg_desc *, const wt_seg_desc *, int, float *, boo
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
                          hipStream_t);
 int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, int64_t, int64_t, int, int, int, float,
-                  const int32_t *, const int32_t *, const int32_t *, int, const int32_t *, const int32_t *, void *, int, int64_t,
-                  int64_t, int64_t, hipStream_t);
+                  const int32_t *, const int32_t *, const int32_t *, int, const int32_t *, const int32_t *, const int32_t *, void *,
+                  int, int64_t, int64_t, int64_t, hipStream_t);
 int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
 int disfluency_batch(const float *, const wt_seg_desc *, int, const int32_t *, int32_t *, double, double, hipStream_t);
 int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
@@ -237,7 +237,21 @@ int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_laye
                      const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_batch_stride,
                      int64_t ring_rows, int64_t ring_row0, void *stream) {
     return wt::qk_rows_batch(q_layers_host, k_layers_host, n_layers, dtype, n_batch, n_q, q_batch_stride, k_batch_stride, n_ctx,
-                             d_model, head_dim, scale, sel_layer, sel_head, sel_slot, n_sel, row_begin, row_end, ring,
+                             d_model, head_dim, scale, sel_layer, sel_head, sel_slot, n_sel, row_begin, row_end, nullptr, ring,
+                             ring_dtype, ring_batch_stride, ring_rows, ring_row0, (hipStream_t)stream);
+}
+
+int wt_qk_rows_streams(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,
+                       int n_q, int64_t q_batch_stride, int64_t k_batch_stride, int n_ctx, int d_model, int head_dim, float scale,
+                       const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
+                       const int32_t *ring_index, void *ring, int ring_dtype, int64_t ring_batch_stride, int64_t ring_rows,
+                       int64_t ring_row0, void *stream) {
+    if (!ring_index) {
+        wt::set_error("wt_qk_rows_streams: ring_index is null");
+        return WT_E_BADARG;
+    }
+    return wt::qk_rows_batch(q_layers_host, k_layers_host, n_layers, dtype, n_batch, n_q, q_batch_stride, k_batch_stride, n_ctx,
+                             d_model, head_dim, scale, sel_layer, sel_head, sel_slot, n_sel, nullptr, nullptr, ring_index, ring,
                              ring_dtype, ring_batch_stride, ring_rows, ring_row0, (hipStream_t)stream);
 }
 

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void qk_rows_batch_kernel(QkLayers L, int n_q,
                                                             const int32_t *__restrict__ sel_head,
                                                             const int32_t *__restrict__ sel_slot,
                                                             const int32_t *__restrict__ row_begin,
-                                                            const int32_t *__restrict__ row_end, DT *__restrict__ ring,
+                                                            const int32_t *__restrict__ row_end,
+                                                            const int32_t *__restrict__ ring_index, DT *__restrict__ ring,
                                                             int64_t ring_bstride, int64_t ring_rows, int64_t ring_row0) {
     __shared__ __attribute__((aligned(16))) float qs[QB_ROWS][HD];
     const int s = blockIdx.y, b = blockIdx.z;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(256) void qk_rows_batch_kernel(QkLayers L, int n_q,
 #pragma unroll
         for (int d = 0; d < HD; ++d) kr[d] = scaled<T>(krow[d], scale);
     }
-    DT *out = ring + (int64_t)b * ring_bstride + ((int64_t)sel_slot[s] * ring_rows + ring_row0) * n_ctx + f;
+    // window b of the batch writes ring block ring_index[b] (streams decoded together need not be neighbours in the ring)
+    const int64_t rb = ring_index ? ring_index[b] : b;
+    DT *out = ring + rb * ring_bstride + ((int64_t)sel_slot[s] * ring_rows + ring_row0) * n_ctx + f;
     for (int r0 = r_lo; r0 < r_hi; r0 += QB_ROWS) {
         const int nr = min(QB_ROWS, r_hi - r0);
         __syncthreads();   // the previous trip's readers are done
@@ -191,8 +194,8 @@ __global__ __launch_bounds__(256) void qk_rows_batch_kernel(QkLayers L, int n_q,
 int qk_rows_batch(const void *const *q_layers, const void *const *k_layers, int n_layers, int dtype, int n_batch, int n_q,
                   int64_t q_bstride, int64_t k_bstride, int n_ctx, int d_model, int head_dim, float scale,
                   const int32_t *sel_layer, const int32_t *sel_head, const int32_t *sel_slot, int n_sel,
-                  const int32_t *row_begin, const int32_t *row_end, void *ring, int ring_dtype, int64_t ring_bstride,
-                  int64_t ring_rows, int64_t ring_row0, hipStream_t st) {
+                  const int32_t *row_begin, const int32_t *row_end, const int32_t *ring_index, void *ring, int ring_dtype,
+                  int64_t ring_bstride, int64_t ring_rows, int64_t ring_row0, hipStream_t st) {
     if (!q_layers || !k_layers || n_layers <= 0 || n_layers > WT_MAX_LAYERS || !sel_layer || !sel_head || !sel_slot || !ring ||
         n_batch < 0 || n_q <= 0 || n_ctx <= 0 || d_model <= 0 || head_dim <= 0 || d_model % head_dim != 0 || n_sel < 0 ||
         ring_row0 < 0 || ring_row0 + n_q > ring_rows) {
@@ -217,7 +220,8 @@ int qk_rows_batch(const void *const *q_layers, const void *const *k_layers, int 
     const dim3 grid((n_ctx + 255) / 256, n_sel, n_batch), block(256);
 #define WT_QKB(ST, DT)                                                                                                   \
     hipLaunchKernelGGL((qk_rows_batch_kernel<ST, DT, 64>), grid, block, 0, st, L, n_q, q_bstride, k_bstride, n_ctx, d_model, \
-                       scale, sel_layer, sel_head, sel_slot, row_begin, row_end, (DT *)ring, ring_bstride, ring_rows, ring_row0)
+                       scale, sel_layer, sel_head, sel_slot, row_begin, row_end, ring_index, (DT *)ring, ring_bstride, ring_rows, \
+                       ring_row0)
     if (dtype == WT_DTYPE_F32 && ring_dtype == WT_DTYPE_F32) WT_QKB(float, float);
     else if (dtype == WT_DTYPE_F32 && ring_dtype == WT_DTYPE_F16) WT_QKB(float, __half);
     else if (dtype == WT_DTYPE_F16 && ring_dtype == WT_DTYPE_F32) WT_QKB(__half, float);

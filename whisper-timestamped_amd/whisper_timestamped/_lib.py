@@ -31,7 +31,7 @@ assert SEG_DTYPE.itemsize == 64
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
            "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3",
-           "wt_release_stream"]
+           "wt_release_stream", "wt_qk_rows_streams"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
 ABI_VERSION = 4
 WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS, WT_ALIGN_ROWS_PER_CLASS = 1, 2, 4
@@ -72,6 +72,8 @@ def load():
     L.wt_logprob_gather_rows.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp]
     L.wt_dtw_batch_pattern.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.wt_release_stream.argtypes = [vp]
+    L.wt_qk_rows_streams.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, f32, vp, vp, vp, i32, vp, vp, i32, i64,
+                                     i64, i64, vp]
     if L.wt_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} exports ABI version {L.wt_version()}, this package needs {ABI_VERSION}: rebuild it "
                           f"(`make -C {_PKG_ROOT}/csrc`)")

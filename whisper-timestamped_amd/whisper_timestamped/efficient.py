@@ -66,7 +66,11 @@ class EfficientSession:
     def __init__(self, model, whisper_options, *, remove_punctuation_from_words, compute_word_confidence,
                  include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
                  word_alignment_most_top_layers, detect_disfluencies, trust_whisper_timestamps,
-                 use_timestamps_for_alignment=True, ring_dtype=None):
+                 use_timestamps_for_alignment=True, ring_dtype=None, ring=None, logits=None, sink=None):
+        """``ring`` / ``logits`` / ``sink``: the B-stream form (streams.py).  One session per decoder stream, fed with the
+        RECORDED events of a batched decoder call instead of live hooks: its attention rows and logits rows live in its
+        block of rings shared by all streams (views handed in here), and the alignment units of all streams of a window
+        set go out in ONE launch set (the sink) instead of one per stream."""
         self.model = model
         self.opts = whisper_options
         self.remove_punctuation_from_words = remove_punctuation_from_words
@@ -93,9 +97,12 @@ class EfficientSession:
         self.hooked_blocks = list(range(n_blocks - top, n_blocks))
         dev = model.device
         _lib.require_gpu(dev)
-        self.ring = QKCaptureRing(dev, head_pairs(alignment_heads), len(self.hooked_blocks), model.dims.n_text_head,
-                                  n_ctx=model.dims.n_audio_ctx, capacity=self.n_ctx, dtype=ring_dtype or RING_DTYPE)
-        self.logits = LogitsRing(dev, model.dims.n_vocab, capacity=self.n_ctx + 1)
+        self.replay = ring is not None
+        self.sink = sink
+        self.ring = ring if ring is not None else \
+            QKCaptureRing(dev, head_pairs(alignment_heads), len(self.hooked_blocks), model.dims.n_text_head,
+                          n_ctx=model.dims.n_audio_ctx, capacity=self.n_ctx, dtype=ring_dtype or RING_DTYPE)
+        self.logits = logits if logits is not None else LogitsRing(dev, model.dims.n_vocab, capacity=self.n_ctx + 1)
         self.embedding_t = None
 
         # outcome
@@ -137,8 +144,10 @@ class EfficientSession:
         self.in_flight = []              # [(AlignmentBatch, [placeholder word lists])] launched, not yet read
         self._pad_handles = {}           # id(mfcc) -> (mfcc, HostCopy of find_start_padding): queued when the mel appears
         # every decoder input of the window, device resident (the logit filters' `tokens` argument)
-        self.ctx_buf = torch.zeros((1, 2 * self.n_ctx + 8), dtype=torch.int64, device=dev)
+        self.ctx_buf = None if self.replay else torch.zeros((1, 2 * self.n_ctx + 8), dtype=torch.int64, device=dev)
         self.ctx_len = 0
+        if self.replay:                      # the driver has verified the batch's rows; a stream only reads them
+            self.reuse = True
 
     # ------------------------------------------------------------------ small predicates
     def _is_sot(self, cur):
@@ -173,8 +182,13 @@ class EfficientSession:
 
     def hook_tokens(self, layer, ins, outs):
         cur = ins[0]
+        # one decoder stream per session (T.py:806); B streams stepping together = B sessions fed by streams.py
         assert cur.shape[0] == 1, "Batch decoding is not supported"
-        cur = cur[0].tolist()                     # the per-step host read whisper's own loop needs anyway
+        self.on_tokens(cur[0].tolist(), ins[0][0])    # the per-step host read whisper's own loop needs anyway
+
+    def on_tokens(self, cur, cur_device=None):
+        """One decoder call of this stream: ``cur`` = its input token ids (a list; the prompt of a new window, or the one
+        token sampled at the previous step)."""
         self._commit_pending_logits()             # (REUSE_DECODER_LOGITS) the previous step's row is final by now
         tk = self.tokenizer
         sot = self._is_sot(cur)
@@ -184,7 +198,8 @@ class EfficientSession:
                 self.opts["language"] = self.language
                 self.detected_language = True
             n_sot = len(tk.sot_sequence)
-            self.logit_filters = backend.get_logit_filters(self.model, self.opts, prompt=cur[1:-n_sot])
+            if not self.replay:                   # (only the reference-way rows need the filters)
+                self.logit_filters = backend.get_logit_filters(self.model, self.opts, prompt=cur[1:-n_sot])
         self._may_flush(cur)
         if sot:
             self.has_started = len(cur) > 1 or not self.model.is_multilingual
@@ -198,7 +213,8 @@ class EfficientSession:
             self.open_rows.append(self.row_next)
             self.row_next += 1
             self.window_inputs.append(cur)
-            self.ctx_buf[0, self.ctx_len:self.ctx_len + len(cur)] = ins[0][0]      # device -> device, no host list
+            if self.ctx_buf is not None:
+                self.ctx_buf[0, self.ctx_len:self.ctx_len + len(cur)] = cur_device     # device -> device, no host list
             self.ctx_len += len(cur)
             if not sot:
                 self.window_tokens_nosot.append(cur[-1])
@@ -274,7 +290,7 @@ class EfficientSession:
         if self.reuse == "auto" and self.reuse_state == "verify":
             row = self._verified(row)
         self.logits.append(row)
-        if self.reuse is True and len(self.logits) == 1 and self.tokenizer.no_timestamps is not None:
+        if self.reuse is True and not self.replay and len(self.logits) == 1 and self.tokenizer.no_timestamps is not None:
             # once per window: the row must carry the sampler's in-place filtering (<|notimestamps|> is always -inf)
             if not bool(torch.isinf(self.logits.buf[0, self.tokenizer.no_timestamps])):
                 raise RuntimeError("REUSE_DECODER_LOGITS: this backend does not filter the decoder's logits in place; "
@@ -471,6 +487,10 @@ class EfficientSession:
         """The window is closed: ONE launch set for all of its segments (their QK rows are still in the ring: the
         kernels are queued on the stream before the next window's tokens overwrite them), then read the PREVIOUS
         window's record -- that copy was queued a whole window ago, the wait does not stall anything."""
+        if self.sink is not None:              # B streams: the driver launches ONE set for every stream's units
+            self.sink.take(self.queued)
+            self.queued = []
+            return
         previous, self.in_flight = self.in_flight, []
         if self.queued:
             batch = AlignmentBatch(workspace=self.workspace)
@@ -495,6 +515,10 @@ class EfficientSession:
                     w["start"], w["end"] = r["start"], r["end"]
 
     def _resolve_all(self):
+        if self.sink is not None:
+            self._launch_queued()
+            self.sink.resolve()
+            return
         self._launch_queued()
         pending, self.in_flight = self.in_flight, []
         self._collect(pending)
@@ -706,10 +730,17 @@ class EfficientSession:
             for h in hooks + self._value_hooks:
                 h.remove()
             self._value_hooks = []
-        self._commit_pending_logits()
-        self._may_flush()
+        self.end_of_stream()
         if self.defer:
             self._resolve_all()                   # the last window's record
+        return self.compiled(transcription)
+
+    def end_of_stream(self):
+        """The backend has returned: the last decoder call's row, the last open segment (T.py:913)."""
+        self._commit_pending_logits()
+        self._may_flush()
+
+    def compiled(self, transcription):
         self.segment_tokens.pop(-1)
         LAST_SESSION.clear()
         LAST_SESSION.update(self.stats, reuse_state=self.reuse_state)
