@@ -723,8 +723,8 @@ def parse_args(argv=None):
     # --- process plumbing (see orchestrate()): the measuring legs run in child processes of this script
     ap.add_argument("--role", default="orchestrate", choices=["orchestrate", "kernel", "cpu", "e2e"], help=argparse.SUPPRESS)
     ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient"], help=argparse.SUPPRESS)
-    ap.add_argument("--e2e-workers", type=int, default=2,
-                    help="worker processes per GPU of the default-strategy leg (sharding.transcribe_many)")
+    ap.add_argument("--e2e-streams", type=int, default=32,
+                    help="recordings per decoder op of the default-strategy leg (transcribe_batch; 32 = BASELINE configs[1])")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--secondary", action="store_true", help=argparse.SUPPRESS)     # a kernel leg of another BASELINE config
     ap.add_argument("--dry-run", action="store_true",
@@ -1057,25 +1057,130 @@ def role_cpu(args):
 
 def run_efficient_leg(args, emit):
     """The DEFAULT strategy of transcribe() (the reference's efficient strategy: word alignment on the fly while the
-    backend decodes, T.py:359-1001), 30 s synthetic clips with a scripted ~110-token transcript in 5 segments on the whisper
-    double: one process (what a caller of the reference's API gets: the backend's Python loop, one stream, one token at
-    a time) and `--e2e-workers` worker processes sharing the GPU (sharding.transcribe_many: recordings are independent
-    units).  Timed between a common start after every worker's warm-up clip and the slowest worker's last result."""
+    backend decodes, T.py:359-1001) on 30 s synthetic clips with a scripted ~110-token transcript in 5 segments, whisper
+    double as the model:
+      1_stream        what a caller of the reference's API gets per process: transcribe(model, clip), one decoder stream,
+                      one token at a time through the backend's own Python loop;
+      B_streams       transcribe_batch(model, clips): B independent recordings stepping through the decoder together
+                      (whisper_timestamped/streams.py), B = --e2e-streams (32 = BASELINE configs[1]'s batch);
+      cpu_baseline    the reference-shaped CPU path for the same clips: the same model on the host cores, unfused
+                      attention with per-token QK capture, a second projection + logit filters per token, one
+                      synchronous alignment per segment through oracle/ (the reference's shape, T.py:783-793,849-881,
+                      544-557), one stream -- a bounded sample;
+      parity          every B-stream recording against the one-stream output (texts, word times, confidences) and the
+                      sampled clips against the CPU path's."""
     import many_helper as H          # tests/: the whisper double as the model, the scripted transcript
-    from whisper_timestamped.sharding import transcribe_many
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    from golden import make_golden_transcribe as G
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams
+    dev = "cuda:0"
+    model = H.load_base(dev)
+    B = args.e2e_streams
     g = torch.Generator().manual_seed(7)
-    clip = (0.05 * torch.randn(30 * 16000, generator=g)).float()
+    clips = [(0.05 * torch.randn(30 * 16000, generator=g)).float() for _ in range(4)]
+    segs = [(s, [None] * n, e) for s, n, e in H.SEGMENTS]
+    window = G.window_script(50364, 50257, segs, "eot")
     out = {"workload": "whisper-base (random init, fp32), 30 s synthetic clips, scripted transcript of ~110 tokens in 5 "
                        "timestamped segments, transcribe() with its defaults (efficient strategy, greedy)"}
-    for workers, per_worker in ((1, 4), (args.e2e_workers, 4)):
-        n = workers * per_worker
-        res, seconds = transcribe_many(H.load_base, [clip] * n, workers_per_gpu=workers, devices=["cuda:0"], on_item=H.script_clip,
-                                       warmup=True, return_timing=True, language="en", fp16=False)
-        n_words = sum(len(s["words"]) for r in res for s in r["segments"])
-        assert n_words > 0
-        out[f"{workers}_process{'es' if workers > 1 else ''}"] = {
-            "audio_s_per_s": round(30.0 * n / seconds, 1), "clips": n, "seconds": round(seconds, 3),
-            "ms_per_clip_per_process": round(1e3 * seconds / per_worker, 1), "words": n_words}
+
+    def words_of(r):
+        return [(w["text"], w["start"], w["end"], w["confidence"]) for s_ in r["segments"] for w in s_["words"]]
+
+    # ---- one stream (the reference's shape of the call)
+    def one(clip):
+        set_script(Script([window]))
+        try:
+            return wt.transcribe(model, clip, language="en", fp16=False)
+        finally:
+            set_script(None)
+    one(clips[0])                                           # warm-up: allocations, GEMM plans, the library's arenas
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    singles = [one(c) for c in clips]
+    torch.cuda.synchronize()
+    el1 = time.perf_counter() - t0
+    n_words = sum(len(words_of(r)) for r in singles)
+    assert n_words > 0
+    out["1_stream"] = {"audio_s_per_s": round(30.0 * len(clips) / el1, 1), "clips": len(clips), "seconds": round(el1, 3),
+                       "ms_per_clip": round(1e3 * el1 / len(clips), 1), "words": n_words}
+    emit(out)
+
+    # ---- B streams per decoder op
+    def many(n):
+        scripts = [Script([window]) for _ in range(n)]
+
+        def on_group(idx):
+            for i in idx:
+                scripts[i].begin_window()
+            set_row_scripts([scripts[i] for i in idx])
+        streams.ON_GROUP_DECODE = on_group
+        try:
+            return wt.transcribe_batch(model, [clips[k % len(clips)] for k in range(n)], max_streams=n, language="en", fp16=False)
+        finally:
+            streams.ON_GROUP_DECODE = None
+            set_row_scripts(None)
+    many(B)                                                 # warm-up at the timed shape
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        batch = many(B)
+    torch.cuda.synchronize()
+    elB = (time.perf_counter() - t0) / reps
+    worst_t = worst_c = 0.0
+    for k, r in enumerate(batch):
+        a, b = words_of(r), words_of(singles[k % len(clips)])
+        assert [x[0] for x in a] == [x[0] for x in b], "B-stream and one-stream words differ"
+        worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
+        worst_c = max([worst_c] + [abs(x[3] - y[3]) for x, y in zip(a, b)])
+    out[f"{B}_streams"] = {"audio_s_per_s": round(30.0 * B / elB, 1), "clips": B, "seconds": round(elB, 3),
+                           "ms_per_clip": round(1e3 * elB / B, 2), "words": sum(len(words_of(r)) for r in batch),
+                           "speedup_vs_1_stream": round((30.0 * B / elB) / (30.0 * len(clips) / el1), 2),
+                           "driver": dict(streams.LAST_RUN),
+                           "parity_vs_1_stream": {"max_abs_dt_word_s": round(worst_t, 4), "max_abs_dconfidence": round(worst_c, 6)}}
+    assert worst_t <= 0.02 + 1e-9 and worst_c <= 1e-3 + 1e-9, out[f"{B}_streams"]
+    emit(out)
+
+    # ---- the reference-shaped CPU path, same clips (bounded sample)
+    if not args.no_cpu_baseline:
+        import cpu_kernel_standin
+        from whisper_timestamped import efficient
+        saved = {k: getattr(efficient, k) for k in ("REUSE_DECODER_LOGITS", "DEFER_ALIGNMENT", "GPU_FRONT_END", "FUSED_ATTENTION")}
+        patch = H._Undo()
+        try:
+            cpu_kernel_standin.install(patch)              # kernels -> oracle/, unfused attention, backend's own log-mel
+            efficient.REUSE_DECODER_LOGITS = False         # a second projection + filters per token (T.py:871-874)
+            efficient.DEFER_ALIGNMENT = False              # one synchronous alignment per segment (T.py:544-557)
+            model_cpu = H.load_base("cpu")
+            done, t0, worst_t = 0, time.perf_counter(), 0.0
+            while done < len(clips):
+                set_script(Script([window]))
+                try:
+                    r = wt.transcribe(model_cpu, clips[done], language="en", fp16=False)
+                finally:
+                    set_script(None)
+                a, b = words_of(r), words_of(singles[done])
+                assert [x[0] for x in a] == [x[0] for x in b], "GPU and CPU words differ"
+                worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
+                done += 1
+                if time.perf_counter() - t0 > args.e2e_cpu_budget:
+                    break
+            el = time.perf_counter() - t0
+        finally:
+            patch.undo()
+            for k, v in saved.items():
+                setattr(efficient, k, v)
+        out["cpu_baseline"] = {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s", "cores": int(torch.get_num_threads()),
+                               "kind": "port",
+                               "sample": f"{done} of the same clips, one stream: the same whisper-base on the CPU, unfused attention "
+                                         f"with per-token QK capture, second projection + logit filters per token, one alignment "
+                                         f"per segment through oracle/, {el:.1f} s wall"}
+        out["parity_vs_cpu_reference_path"] = {"clips": done, "max_abs_dt_word_s": round(worst_t, 4)}
+        out["speedup_vs_cpu"] = {"1_stream": round(out["1_stream"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1),
+                                 f"{B}_streams": round(out[f"{B}_streams"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)}
         emit(out)
     return out
 

@@ -39,6 +39,22 @@ class _Patch:
         setattr(obj, name, value)
 
 
+class _Undo(_Patch):
+    """...and its undo (bench.py's CPU baseline of the default strategy installs the stand-in for one leg only)."""
+
+    def __init__(self):
+        self.saved = []
+
+    def setattr(self, obj, name, value):
+        self.saved.append((obj, name, getattr(obj, name)))
+        setattr(obj, name, value)
+
+    def undo(self):
+        for obj, name, value in reversed(self.saved):
+            setattr(obj, name, value)
+        self.saved = []
+
+
 _STANDIN = False
 
 

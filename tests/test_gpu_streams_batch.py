@@ -1,0 +1,85 @@
+"""transcribe_batch (whisper_timestamped/streams.py) on the MI355X: B recordings per decoder op, real kernels
+(wt_qk_rows_streams, wt_align_batch_v3, wt_logprob_gather_rows, wt_find_start_padding_batch, wt_logmel_batch).
+
+Bars (BASELINE.json north_star, as tests/test_gpu_transcribe.py): against the REFERENCE's output for every recording --
+word times within 0.02 s, confidences within 1e-4 before rounding, mean log-probabilities within 2e-4 -- and against
+this repository's own one-stream path: a batch of eight equals eight single calls word for word and time for time.
+"""
+import copy
+import json
+
+import pytest
+import torch
+
+from golden import make_golden_transcribe as G
+from test_streams_host import BATCHABLE, run_batch, same_model_cases
+from test_transcribe_host import CASES, LOGPROB_TOL, compare, is_sampled, raw_confidence_gap, raw_logprob_gap, rounded, run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_against_reference(raw, case):
+    compare(rounded(raw), case["expected"], time_tol=0.02, conf_tol=1e-3 + 1e-4, logprob_tol=2e-4, sampled=is_sampled(case))
+    assert raw_confidence_gap(raw, case) <= 1e-4
+    assert raw_logprob_gap(raw, case) <= LOGPROB_TOL
+
+
+@pytest.mark.parametrize("case", BATCHABLE, ids=[c["name"] for c in BATCHABLE])
+def test_a_batch_of_one_stream_matches_the_reference(case):
+    _check_against_reference(run_batch([copy.deepcopy(case)], device="cuda:0")[0], case)
+
+
+def test_eight_ragged_streams_each_match_the_reference():
+    from whisper_timestamped import streams
+    cases = same_model_cases() + same_model_cases()[::-1]
+    for raw, case in zip(run_batch(cases, device="cuda:0"), cases):
+        _check_against_reference(raw, case)
+    assert streams.LAST_RUN["streams"] == 8 and streams.LAST_RUN["alignment_launch_sets"] <= streams.LAST_RUN["rounds"] + 1
+
+
+def test_a_batch_of_eight_equals_eight_single_calls():
+    """The same recordings through transcribe() one at a time (B = 1: the backend's own loop, live hooks) and through
+    transcribe_batch: same texts, same segmentation, same word times (exactly), confidences within GEMM batch-size
+    rounding."""
+    cases = same_model_cases() + same_model_cases()
+    singles = [run_case(copy.deepcopy(c), device="cuda:0", raw_confidence=True) for c in cases]
+    batch = run_batch(cases, device="cuda:0")
+    for b, s in zip(batch, singles):
+        compare(b, s, time_tol=0.0, conf_tol=2e-5, logprob_tol=1e-4)
+
+
+def test_half_precision_model_streams_stay_close():
+    """fp16=True (the reference's GPU default): the batch against its own one-stream run, same precision."""
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams
+    cases = same_model_cases()[:3]
+    model, _, _ = G.build_case(cases[0], device="cuda:0")
+    audios = [G.build_case(c, device="cuda:0")[1] for c in cases]
+    singles = []
+    for c, a in zip(cases, audios):
+        set_script(Script(c["recorded"]))
+        try:
+            singles.append(json.loads(json.dumps(G.public_view(wt.transcribe(model, a, fp16=True, **c["opts"])), default=float)))
+        finally:
+            set_script(None)
+    scripts = [Script(c["recorded"]) for c in cases]
+
+    def on_group(idx):
+        for i in idx:
+            scripts[i].begin_window()
+        set_row_scripts([scripts[i] for i in idx])
+    streams.ON_GROUP_DECODE = on_group
+    try:
+        batch = wt.transcribe_batch(model, audios, fp16=True, **cases[0]["opts"])
+    finally:
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    for b, s in zip(batch, singles):
+        b = json.loads(json.dumps(G.public_view(b), default=float))
+        assert [w["text"] for x in b["segments"] for w in x["words"]] == [w["text"] for x in s["segments"] for w in x["words"]]
+        dts = [abs(a[k] - c[k]) for x, y in zip(b["segments"], s["segments"]) for a, c in zip(x["words"], y["words"])
+               for k in ("start", "end")]
+        assert max(dts) <= 0.04 + 1e-9, max(dts)        # half-precision rows: two frames

@@ -1,0 +1,130 @@
+"""whisper_timestamped.transcribe_batch (streams.py): B independent recordings stepping through the decoder together,
+against the REFERENCE'S OWN OUTPUT for each of them (tests/golden/transcribe_cases.json: what /root/reference's
+transcribe_timestamped produced, one recording at a time).
+
+No GPU here: kernels = the CPU oracle (tests/cpu_kernel_standin.py), so what is checked is the host side of the B-stream
+form -- the lock-step window driver (openai-whisper's transcribe() loop restated per stream), the recorded-calls replay
+into every stream's EfficientSession, the shared rings and the one-launch-set-per-window-set sink -- on every branch the
+goldens reach.  The same tests run with the real kernels in tests/test_gpu_streams_batch.py.
+"""
+import copy
+import json
+
+import pytest
+import torch
+
+import cpu_kernel_standin
+from golden import make_golden_transcribe as G
+from test_transcribe_host import CASES, compare, raw_confidence_gap, raw_logprob_gap, rounded
+
+BATCHABLE = [c for c in CASES if not (c["opts"].get("naive_approach") or c["opts"].get("beam_size") or c["opts"].get("best_of")
+                                      or isinstance(c["opts"].get("temperature"), (list, tuple)) or c["opts"].get("vad"))]
+
+
+def install_streams_standin(monkeypatch):
+    """The oracle-backed stand-in for the one kernel entry streams.py adds to what cpu_kernel_standin covers."""
+    from whisper_timestamped import streams
+
+    def write_qk(self, q_layers, k_layers, ring_index, row):
+        sl, sh, ss = (t.tolist() for t in self.sel)
+        scale = 64 ** -0.25
+        for i, h, s in zip(sl, sh, ss):
+            l = self.used[i]
+            q = q_layers[l][:, -1:, h * 64:(h + 1) * 64] * scale
+            k = k_layers[l][:, :, h * 64:(h + 1) * 64] * scale
+            self.qk[ring_index.long(), s, row] = (q @ k.transpose(1, 2))[:, 0].float().to(self.qk.dtype)
+    monkeypatch.setattr(streams.StreamRings, "write_qk", write_qk)
+
+
+def run_batch(cases, device="cpu", raw_confidence=True, max_streams=32, **extra):
+    """transcribe_batch on the recordings of `cases` (same model, same options), every stream's sampler steered by its
+    own recorded script.  -> list of public views."""
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams, words
+    model = audios = None
+    audios = []
+    for c in cases:
+        m, audio, _ = G.build_case(c, device=device)
+        model = model or m
+        audios.append(audio)
+    scripts = [Script(c["recorded"]) for c in cases]
+    base = [0]
+
+    def on_group(idx):
+        for i in idx:
+            scripts[base[0] + i].begin_window()
+        set_row_scripts([scripts[base[0] + i] for i in idx])
+    set_script(None)
+    streams.ON_GROUP_DECODE = on_group
+    words.RAW_CONFIDENCE = bool(raw_confidence)
+    try:
+        results = []
+        for a in range(0, len(audios), max_streams):     # (the driver numbers streams per chunk of max_streams)
+            base[0] = a
+            results += wt.transcribe_batch(model, audios[a:a + max_streams], fp16=False, max_streams=max_streams,
+                                           **cases[0]["opts"], **extra)
+    finally:
+        words.RAW_CONFIDENCE = False
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    for c, sc in zip(cases, scripts):
+        assert sc.record == c["recorded"], c["name"]
+    return [json.loads(json.dumps(G.public_view(r), default=float)) for r in results]
+
+
+@pytest.mark.parametrize("case", BATCHABLE, ids=[c["name"] for c in BATCHABLE])
+def test_a_batch_of_one_stream_equals_the_reference(case, monkeypatch):
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    raw = run_batch([copy.deepcopy(case)])[0]
+    compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-6)
+    assert raw_confidence_gap(raw, case) <= 1e-5 and raw_logprob_gap(raw, case) <= 2e-5
+
+
+def same_model_cases():
+    names = ("one_window_two_segments", "two_windows_prompted", "eot_without_end_timestamp", "empty_first_window")
+    return [copy.deepcopy(next(c for c in CASES if c["name"] == n)) for n in names]
+
+
+def test_streams_of_different_lengths_each_equal_the_reference(monkeypatch):
+    """Four recordings of 9 to 47 s (one or two windows, different prompts in the second round) + the same four again:
+    8 streams, ragged rounds, groups by prompt length -- every stream must reproduce the reference's output for it."""
+    from whisper_timestamped import streams
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    cases = same_model_cases() + same_model_cases()[::-1]
+    views = run_batch(cases)
+    for raw, case in zip(views, cases):
+        compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+        assert raw_confidence_gap(raw, case) <= 1e-5 and raw_logprob_gap(raw, case) <= 2e-5
+    assert streams.LAST_RUN["streams"] == 8 and streams.LAST_RUN["rounds"] >= 2
+    # ONE alignment launch set per round (+ the final one), not one per stream and window
+    assert streams.LAST_RUN["alignment_launch_sets"] <= streams.LAST_RUN["rounds"] + 1
+
+
+def test_more_recordings_than_streams(monkeypatch):
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    cases = same_model_cases()
+    views = run_batch(cases, max_streams=3)
+    for raw, case in zip(views, cases):
+        compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+
+
+def test_calls_the_batched_path_cannot_take_run_one_by_one(monkeypatch):
+    """beam search / temperature fallback / vad belong to the naive strategy or pre-processing: transcribe_batch hands
+    them to transcribe_timestamped, recording by recording (same results, no batching)."""
+    import whisper_double as W
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams
+    assert not streams.supports(dict(temperature=(0.0, 0.2)), None, False)
+    assert not streams.supports(dict(temperature=0.0, beam_size=5), None, True)
+    assert not streams.supports(dict(temperature=0.0), [(0.0, 1.0)], False)
+    assert streams.supports(dict(temperature=0.0, best_of=None, beam_size=None), None, False)
+    with pytest.raises(AssertionError, match="unknown options"):
+        wt.transcribe_batch(None, [torch.zeros(16000)], not_an_option=1)
+    assert wt.transcribe_batch(None, []) == []

@@ -56,12 +56,20 @@ class Script:
 
 
 _SCRIPT: Optional[Script] = None
+_ROW_SCRIPTS: Optional[list] = None      # B streams in one decoder loop: one Script (or None) per batch row
 
 
 def set_script(script: Optional[Script]):
     global _SCRIPT
     _SCRIPT = script
     return script
+
+
+def set_row_scripts(scripts: Optional[list]):
+    """Batched decoding (whisper_timestamped.streams): row k of the next decoder loops is steered by scripts[k].  The
+    caller starts each script's window (``begin_window``) itself: the loop is entered below ``DecodingTask.run``."""
+    global _ROW_SCRIPTS
+    _ROW_SCRIPTS = list(scripts) if scripts is not None else None
 
 
 # ---------------------------------------------------------------------------
@@ -177,7 +185,13 @@ class GreedyDecoder:
             next_tokens = logits.argmax(dim=-1)
         else:
             next_tokens = Categorical(logits=logits / self.temperature).sample()
-        if _SCRIPT is not None and tokens.shape[0] == 1:    # (several hypotheses: forced at the result level, see run())
+        if _ROW_SCRIPTS is not None:
+            assert len(_ROW_SCRIPTS) == tokens.shape[0], (len(_ROW_SCRIPTS), tokens.shape)
+            done = (tokens[:, -1] == self.eot).tolist()     # a finished row is fed eot from now on: its script is over
+            next_tokens = torch.tensor([int(t) if (sc is None or done[k]) else sc.pick(int(t), logits[k], self.eot)
+                                        for k, (t, sc) in enumerate(zip(next_tokens.tolist(), _ROW_SCRIPTS))],
+                                       device=logits.device)
+        elif _SCRIPT is not None and tokens.shape[0] == 1:    # (several hypotheses: forced at the result level, see run())
             next_tokens = torch.tensor([_SCRIPT.pick(int(t), logits[k], self.eot) for k, t in enumerate(next_tokens.tolist())],
                                        device=logits.device)
         logprobs = F.log_softmax(logits.float(), dim=-1)

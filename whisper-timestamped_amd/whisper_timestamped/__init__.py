@@ -9,7 +9,7 @@ from .alignment import AlignmentBatch, AlignmentUnit, perform_word_alignment, pr
 from .words import (split_tokens_on_spaces, split_tokens_on_unicode, round_confidence, round_timestamp)  # noqa: F401
 from .capture import LogitsRing, QKCaptureRing  # noqa: F401
 from .postprocess import ensure_increasing_positions, remove_last_null_duration_words  # noqa: F401
-from .transcribe import get_alignment_heads, load_model, transcribe, transcribe_timestamped  # noqa: F401
+from .transcribe import get_alignment_heads, load_model, transcribe, transcribe_batch, transcribe_timestamped  # noqa: F401
 
 # The reference re-exports a set of openai-whisper names (its __init__.py:1-5).  openai-whisper is an optional,
 # lazily imported backend here, so they are resolved on first access; `audio`, `log_mel_spectrogram`, `pad_or_trim`

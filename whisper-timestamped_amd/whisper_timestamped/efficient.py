@@ -162,13 +162,18 @@ class EfficientSession:
         return tok >= self.tokenizer.timestamp_begin
 
     # ------------------------------------------------------------------ hooks
-    def hook_mel(self, layer, ins, outs):
+    def hook_mel(self, layer, ins, outs, pad_handle=None):
+        """``pad_handle`` (streams.py): an object whose ``wait()[0]`` is find_start_padding of this window, computed for
+        all streams of a round in one launch; without it the detector is queued here for this window alone."""
         self.new_mfcc = ins[0]
         if self.mfcc is None:
             self.mfcc = self.new_mfcc
         if self.defer:                    # where this window's zero padding starts: on the host long before it is needed
             self._pad_handles = {k: v for k, v in self._pad_handles.items() if v[0] is self.mfcc}
-            self._padding_handle(self.new_mfcc)
+            if pad_handle is not None:
+                self._pad_handles[id(self.new_mfcc)] = (self.new_mfcc, pad_handle)
+            else:
+                self._padding_handle(self.new_mfcc)
 
     def _padding_handle(self, mfcc):
         """(mfcc, asynchronous host copy of find_start_padding(mfcc)) -- queued once per window's mel."""

@@ -1,0 +1,635 @@
+"""The efficient strategy for B INDEPENDENT recordings at once: B decoder streams per decoder op.
+
+The reference's efficient strategy (/root/reference/whisper_timestamped/transcribe.py:359-1001, "T.py" below) hooks
+openai-whisper's own ``transcribe()`` loop, which decodes ONE stream token by token (T.py:806 asserts a batch of one):
+on an MI355X that is ~2.7 ms of host Python per token around a few hundred microseconds of GPU work.
+Recordings are independent units, so here B of them step through the decoder TOGETHER:
+
+  * a lock-step window driver: every round each active stream contributes its next 30 s window (its own seek, its own
+    prompt); streams whose initial token rows have the same length share ONE batched decoder loop -- the backend's own
+    ``DecodingTask._main_loop`` (KV cache, logit filters, sampler), entered with one row of initial tokens PER STREAM
+    instead of ``DecodingTask.run``'s one row repeated.  The seek / prompt / no-speech / segment-splitting logic around
+    it is openai-whisper's ``transcribe()`` loop restated per stream (whisper/transcribe.py; third-party, absent from
+    the build image: SURVEY.md Appendix C) for the option domain of the efficient strategy: greedy or single-temperature
+    sampling, no temperature fallback, no beam (those go to the naive strategy: T.py:243-252), no ``vad``;
+  * the data plane of the decode-time hooks for all streams of a decoder call: ONE ``wt_qk_rows_streams`` launch per
+    token writes the alignment heads' QK rows of every stream into its block of a (B, A_sel, n_ctx_text, 1500) ring,
+    ONE copy per token moves the (B, V) rows the sampler has just filtered into a (B, n_ctx_text + 1, V) ring, ONE
+    ``wt_logprob_gather_rows`` per decoder loop produces every stream's chosen-token log-probabilities, ONE
+    ``wt_find_start_padding_batch`` serves all windows of a round;
+  * per stream an unmodified ``EfficientSession`` (efficient.py: the reference's hook state machine, decision by
+    decision) that is fed the RECORDED decoder calls of its stream -- the same methods in the same order as the live
+    hooks would call them -- and whose alignment units go into ONE ``AlignmentBatch`` per window set (the sink).
+
+Ordering, which is what makes the rings safe to recycle: the first decoder call of a window (its prompt) is what
+flushes the previous window's last segment and closes that window (T.py:824, Appendix B of SURVEY.md), and the prompt
+is known to the driver BEFORE the batched loop runs.  So a round is: mel windows -> padding detector -> every active
+stream's prompt call replayed (previous window flushed and closed, its units queued) -> ONE alignment launch set ->
+the batched decoder loops (which overwrite the rings: the kernels that read the old rows are already queued on the
+same HIP stream) -> the remaining recorded calls replayed.
+
+Results: for a given stream the host logic is byte for byte the B = 1 code; the numerics differ from a B = 1 run only
+through the batch size of the backend's GEMMs (tests: B = 8 equals eight B = 1 runs word for word, time for time).
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib, backend, efficient
+from .alignment import AlignmentBatch, default_workspace, head_pairs
+from .capture import layer_head_slots
+from .efficient import EfficientSession
+from .words import HOP_LENGTH, N_FRAMES, SAMPLE_RATE
+
+logger = logging.getLogger("whisper_timestamped")
+
+N_SAMPLES = 30 * SAMPLE_RATE
+# test / instrumentation seam: called with the stream indices of a batched decoder loop right before it starts
+ON_GROUP_DECODE = None
+LAST_RUN = {}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# device rings of B streams
+# ----------------------------------------------------------------------------------------------------------------------
+class _QKView:
+    """What an EfficientSession needs of a QKCaptureRing, on one stream's block of the shared ring."""
+
+    def __init__(self, buf):
+        self.buf = buf                      # (A_sel, capacity, n_ctx)
+        self.device = buf.device
+
+    def rows(self, rows):
+        rows = list(rows)
+        if rows and rows == list(range(rows[0], rows[0] + len(rows))):
+            return self.buf[:, rows[0]:rows[0] + len(rows)]
+        return self.buf.index_select(1, torch.tensor(rows, dtype=torch.long, device=self.device))
+
+
+class _LogitsView:
+    """What an EfficientSession needs of a LogitsRing, on one stream's block.  The rows are written by the driver (all
+    streams of a decoder call at once); ``append`` only advances the stream's own count.  ``gather`` is served from the
+    log-probabilities the driver computed for ALL streams of the loop in one launch, as long as the tokens asked for
+    are the tokens that were sampled (else -- the reference's fallbacks for a stuck decoder -- by the kernel)."""
+
+    def __init__(self, buf):
+        self.buf = buf                      # (capacity, V)
+        self.n = 0
+        self.known = None                   # (tokens, logprobs) of the loop just decoded: host lists / fp32 array
+
+    def reset(self):
+        self.n = 0
+
+    def append(self, row):
+        self.n += 1
+
+    def __len__(self):
+        return self.n
+
+    def argmax(self, row, lo=0):
+        if row < 0:
+            row += self.n
+        return int(torch.argmax(self.buf[row, lo:]).item()) + lo
+
+    def gather(self, tokens):
+        n = len(tokens)
+        assert n <= self.n
+        if self.known is not None and list(self.known[0][:n]) == [int(t) for t in tokens]:
+            return torch.from_numpy(np.array(self.known[1][:n], dtype=np.float32))
+        return _lib.logprob_gather(self.buf[:n], torch.as_tensor(tokens, dtype=torch.int32))
+
+
+class StreamRings:
+    """(B, A_sel, capacity, n_ctx) QK logits of the alignment heads + (B, capacity + 1, V) filtered logits."""
+
+    def __init__(self, model, alignment_heads, hooked_blocks, n_streams, dtype):
+        dev = model.device
+        dims = model.dims
+        self.device = dev
+        self.n_streams, self.capacity, self.n_ctx = n_streams, dims.n_text_ctx, dims.n_audio_ctx
+        per_layer, self.n_slots = layer_head_slots(head_pairs(alignment_heads), len(hooked_blocks), dims.n_text_head)
+        self.used = [l for l, (h, _) in enumerate(per_layer) if h]
+        sel = [(i, h, s) for i, l in enumerate(self.used) for h, s in zip(*per_layer[l])]
+        self.sel = tuple(torch.tensor([x[k] for x in sel], dtype=torch.int32, device=dev) for k in range(3))
+        self.n_sel = len(sel)
+        self.qk = torch.zeros((n_streams, max(self.n_slots, 1), self.capacity, self.n_ctx), dtype=dtype, device=dev)
+        self.logits = torch.empty((n_streams, self.capacity + 1, dims.n_vocab), dtype=torch.float32, device=dev)
+        self._dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[dtype]
+        self._lib = _lib.load()
+        import ctypes as C
+        self._qp, self._kp = (C.c_void_p * len(self.used))(), (C.c_void_p * len(self.used))()
+
+    def write_qk(self, q_layers, k_layers, ring_index, row):
+        """The LAST query row of every selected head, for every stream of the call: q (g, n_q, D), K (g, n_ctx, D) per
+        used layer; ring_index: device int32[g] = each batch entry's stream block."""
+        if self.n_sel == 0:
+            return
+        q0, k0 = q_layers[self.used[0]], k_layers[self.used[0]]
+        g, n_q, D = q0.shape
+        assert q0.stride(2) == 1 and q0.stride(1) == D and k0.shape == (g, self.n_ctx, D) and k0.stride(1) == D and \
+            k0.stride(2) == 1 and k0.dtype == q0.dtype and D % 64 == 0, (q0.shape, k0.shape, q0.dtype)
+        last = (n_q - 1) * D * q0.element_size()
+        for i, l in enumerate(self.used):
+            assert q_layers[l].shape == q0.shape and q_layers[l].stride() == q0.stride() and k_layers[l].stride() == k0.stride()
+            self._qp[i] = q_layers[l].data_ptr() + last
+            self._kp[i] = k_layers[l].data_ptr()
+        dt = _lib.WT_DTYPE_F32 if q0.dtype == torch.float32 else _lib.WT_DTYPE_F16
+        sl, sh, ss = self.sel
+        with _lib.on_device(self.qk) as st:
+            rc = self._lib.wt_qk_rows_streams(self._qp, self._kp, len(self.used), dt, g, 1, q0.stride(0), k0.stride(0), self.n_ctx,
+                                              D, 64, 64.0 ** -0.25, sl.data_ptr(), sh.data_ptr(), ss.data_ptr(), self.n_sel,
+                                              ring_index.data_ptr(), self.qk.data_ptr(), self._dt, self.qk.stride(0),
+                                              self.capacity, int(row), st)
+        _lib._check(rc, "wt_qk_rows_streams")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one AlignmentBatch per window set
+# ----------------------------------------------------------------------------------------------------------------------
+class _Sink:
+    def __init__(self, workspace):
+        self.workspace = workspace
+        self.pending = []                   # (unit, placeholder words, padding handle) of every stream, in arrival order
+        self.in_flight = []
+        self.launch_sets = 0
+
+    def take(self, queued):
+        self.pending.extend(queued)
+
+    def launch(self):
+        """ONE launch set for everything queued since the last one; then the PREVIOUS set's record is read (its copy was
+        queued a whole decoder loop ago)."""
+        previous, self.in_flight = self.in_flight, []
+        if self.pending:
+            batch = AlignmentBatch(workspace=self.workspace)
+            for unit, _, handle in self.pending:
+                if handle is not None:
+                    sp = int(handle[1].wait()[0])
+                    efficient.set_padding(unit, None if sp < 0 else sp)
+                batch.add(unit)
+            batch.launch().fetch()
+            self.launch_sets += 1
+            self.in_flight.append((batch, [ws for _, ws, _ in self.pending]))
+            self.pending = []
+        EfficientSession._collect(previous)
+
+    def resolve(self):
+        self.launch()
+        pending, self.in_flight = self.in_flight, []
+        EfficientSession._collect(pending)
+
+
+class _SliceOfCopy:
+    """handle.wait()[0] for stream j of a shared asynchronous host copy (the padding indices of a whole round)."""
+
+    def __init__(self, shared, j):
+        self.shared, self.j = shared, j
+
+    def wait(self):
+        return self.shared.wait()[self.j:self.j + 1]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# recorder: the hooks of ONE batched decoder loop
+# ----------------------------------------------------------------------------------------------------------------------
+class _Recorder:
+    """Forward hooks for the duration of one ``_main_loop`` over g streams.  Per decoder call it keeps the input token
+    ids (host), writes the QK rows of all streams (one launch) and, one call later -- when the sampler has filtered the
+    previous call's last-position logits in place -- copies those (g, V) rows into the logits ring."""
+
+    def __init__(self, model, rings: StreamRings, hooked_blocks, ring_index, verify: bool):
+        self.model, self.rings, self.hooked_blocks = model, rings, hooked_blocks
+        self.ring_index = ring_index                       # device int32[g]
+        self.ring_index_long = ring_index.long()
+        self.calls = []                                    # per decoder call: list of g token lists
+        self.first_outs = None                             # (g, L, V) logits of the prompt call
+        self.pending = None
+        self.capture = True                                # False during language detection (T.py:828: not started)
+        self.verify = verify
+        self.verify_rows = None
+        self.verified = None
+        self._q = [None] * len(hooked_blocks)
+        self._k = [None] * len(hooked_blocks)
+        self._v = [None] * len(hooked_blocks)
+        self.fused_checked = False
+        self.hooks = []
+
+    def install(self):
+        m = self.model
+        self.hooks.append(m.decoder.token_embedding.register_forward_hook(self.on_tokens))
+        used = self.rings.used
+        for j in used:
+            ca = m.decoder.blocks[self.hooked_blocks[j]].cross_attn
+            self.hooks.append(ca.query.register_forward_hook(lambda mod, i, o, index=j: self._q.__setitem__(index, o)))
+            self.hooks.append(ca.key.register_forward_hook(lambda mod, i, o, index=j: self._k.__setitem__(index, o)))
+            self.hooks.append(ca.value.register_forward_hook(lambda mod, i, o, index=j: self._v.__setitem__(index, o)))
+        if used:
+            ca = m.decoder.blocks[self.hooked_blocks[used[-1]]].cross_attn
+            self.hooks.append(ca.register_forward_hook(self.on_last_cross_attention))
+        self.hooks.append(m.decoder.ln.register_forward_hook(self.on_ln))
+        self.hooks.append(m.decoder.register_forward_hook(self.on_logits))
+        return self
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+        self.hooks = []
+
+    # --- hooks, in firing order within one decoder call
+    def on_tokens(self, layer, ins, outs):
+        self.commit()
+        self.calls.append(ins[0].tolist())                 # the per-step host read whisper's own loop needs anyway
+
+    def on_last_cross_attention(self, layer, ins, outs):
+        if not self.capture:
+            return
+        row = len(self.calls) - 1
+        self.rings.write_qk(self._q, self._k, self.ring_index, row)
+        if not self.fused_checked:
+            self.check_fused_rows(row)
+
+    def on_ln(self, layer, ins, outs):
+        """First call of the loop: the reference-way rows (T.py:871-874: a second projection) kept aside, to be compared
+        with what the sampler leaves in the decoder's own logits (REUSE_DECODER_LOGITS = "auto", efficient.py)."""
+        if self.verify and self.capture and len(self.calls) == 1:
+            e = torch.transpose(self.model.decoder.token_embedding.weight, 0, 1).to(outs.dtype)
+            self.verify_rows = (outs[:, -1, :] @ e).float()
+
+    def on_logits(self, layer, ins, outs):
+        if len(self.calls) == 1:
+            self.first_outs = outs
+        self.pending = outs
+
+    def commit(self):
+        """The previous call's last-position rows are final (the sampler filtered them in place): into the ring."""
+        if self.pending is None or not self.capture:
+            self.pending = None
+            return
+        rows = self.pending[:, -1]
+        step = len(self.calls) - 1
+        if self.verify and step == 0 and self.verify_rows is not None:
+            self.verified = (rows, self.verify_rows)       # compared by the driver with the filters applied
+        self.rings.logits[self.ring_index_long, step] = rows
+        self.pending = None
+
+    def check_fused_rows(self, row):
+        """Once per run (as EfficientSession._check_fused_rows): the rows wt_qk_rows_streams computes from
+        cross_attn.query / .key against the backend's own unfused attention, for the first stream of the call."""
+        self.fused_checked = True
+        worst = 0.0
+        with torch.no_grad(), backend.attention_weights_exposed(True):
+            for index in self.rings.used:
+                if self._v[index] is None:
+                    continue
+                ca = self.model.decoder.blocks[self.hooked_blocks[index]].cross_attn
+                out = ca.qkv_attention(self._q[index][:1, -1:], self._k[index][:1], self._v[index][:1])
+                qk = out[1] if isinstance(out, tuple) and len(out) > 1 else None
+                if qk is None:
+                    continue
+                sl, sh, ss = self.rings.sel
+                mine = (sl == self.rings.used.index(index))
+                want = qk[0, sh[mine].long(), -1].float()
+                got = self.rings.qk[int(self.ring_index[0]), ss[mine].long(), row].float()
+                worst = max(worst, float((got - want).abs().max()))
+        self._v = [None] * len(self.hooked_blocks)
+        q_any = next(q for q in self._q if q is not None)
+        tol = 2e-3 if (q_any.dtype == torch.float32 and self.rings.qk.dtype == torch.float32) else 0.1
+        if not worst <= tol:
+            raise RuntimeError(f"FUSED_ATTENTION self-check failed: the QK rows computed from cross_attn.query/key differ "
+                               f"from the backend's own unfused attention by {worst:.3g} (> {tol})")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one recording
+# ----------------------------------------------------------------------------------------------------------------------
+class _Stream:
+    """openai-whisper's transcribe() loop state of one recording (whisper/transcribe.py: seek, prompt, segments)."""
+
+    def __init__(self, index, mel, content_frames, session, tokenizer, language, initial_prompt_tokens):
+        self.index, self.mel, self.content_frames = index, mel, content_frames
+        self.session, self.tokenizer, self.language = session, tokenizer, language
+        self.seek = 0
+        self.all_tokens = list(initial_prompt_tokens)
+        self.n_initial_prompt = len(initial_prompt_tokens)
+        self.all_segments = []
+        self.prompt_reset_since = 0
+        self.done = content_frames <= 0
+        # the window being decoded
+        self.segment_size = 0
+        self.task = None
+        self.initial_tokens = None
+
+    def active(self):
+        return not self.done and self.seek < self.content_frames
+
+    def window_mel(self):
+        self.segment_size = min(N_FRAMES, self.content_frames - self.seek)
+        seg = self.mel[:, self.seek:self.seek + self.segment_size]
+        if seg.shape[-1] < N_FRAMES:
+            seg = torch.nn.functional.pad(seg, (0, N_FRAMES - seg.shape[-1]))
+        return seg
+
+    def take_result(self, tokens, avg_logprob, no_speech_prob, temperature, opts, w):
+        """What whisper's loop does with the DecodingResult of a window: no-speech skip, segments at consecutive
+        timestamps, seek, prompt bookkeeping."""
+        tk = self.tokenizer
+        input_stride = N_FRAMES // 1500
+        time_precision = input_stride * HOP_LENGTH / SAMPLE_RATE
+        time_offset = float(self.seek * HOP_LENGTH / SAMPLE_RATE)
+        segment_duration = self.segment_size * HOP_LENGTH / SAMPLE_RATE
+        text = tk.decode(tokens).strip()
+        result = dict(temperature=temperature, avg_logprob=avg_logprob, no_speech_prob=no_speech_prob,
+                      compression_ratio=w.utils.compression_ratio(text))
+        nst, lpt = opts["no_speech_threshold"], opts["logprob_threshold"]
+        if nst is not None:
+            should_skip = no_speech_prob > nst
+            if lpt is not None and avg_logprob > lpt:
+                should_skip = False
+            if should_skip:
+                self.seek += self.segment_size
+                return
+        seek0 = self.seek
+
+        def new_segment(start, end, toks):
+            text_tokens = [t for t in toks if t < tk.eot]
+            return {"seek": seek0, "start": start, "end": end, "text": tk.decode(text_tokens), "tokens": list(toks), **result}
+
+        toks = list(tokens)
+        is_ts = [t >= tk.timestamp_begin for t in toks]
+        single_timestamp_ending = is_ts[-2:] == [False, True]
+        consecutive = [i + 1 for i in range(len(toks) - 1) if is_ts[i] and is_ts[i + 1]]
+        current = []
+        if consecutive:
+            slices = list(consecutive)
+            if single_timestamp_ending:
+                slices.append(len(toks))
+            last = 0
+            for cur in slices:
+                sl = toks[last:cur]
+                t0, t1 = sl[0] - tk.timestamp_begin, sl[-1] - tk.timestamp_begin
+                current.append(new_segment(time_offset + t0 * time_precision, time_offset + t1 * time_precision, sl))
+                last = cur
+            if single_timestamp_ending:
+                self.seek += self.segment_size
+            else:
+                self.seek += (toks[last - 1] - tk.timestamp_begin) * input_stride
+        else:
+            duration = segment_duration
+            stamps = [t for t, f in zip(toks, is_ts) if f]
+            if stamps and stamps[-1] != tk.timestamp_begin:
+                duration = (stamps[-1] - tk.timestamp_begin) * time_precision
+            current.append(new_segment(time_offset, time_offset + duration, toks))
+            self.seek += self.segment_size
+        for seg in current:
+            if seg["start"] == seg["end"] or seg["text"].strip() == "":
+                seg["text"], seg["tokens"], seg["words"] = "", [], []
+        self.all_segments.extend({"id": i, **seg} for i, seg in enumerate(current, start=len(self.all_segments)))
+        self.all_tokens.extend(t for seg in current for t in seg["tokens"])
+        if not opts["condition_on_previous_text"] or temperature > 0.5:
+            self.prompt_reset_since = len(self.all_tokens)
+
+    def transcription(self):
+        return dict(text=self.tokenizer.decode(self.all_tokens[self.n_initial_prompt:]), segments=self.all_segments,
+                    language=self.language)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the driver
+# ----------------------------------------------------------------------------------------------------------------------
+def supports(whisper_options, vad=None, naive_approach=False, plot_word_alignment=False):
+    """Can this call take the B-stream path?  (Else: one transcribe_timestamped() per recording.)"""
+    t = whisper_options.get("temperature", 0.0)
+    return not (naive_approach or vad or plot_word_alignment or isinstance(t, (list, tuple)) or
+                whisper_options.get("beam_size") is not None or (whisper_options.get("best_of") or 1) > 1)
+
+
+def _whole_file_mels(model, audios, dtype):
+    """Every recording's log-mel over the whole file + 30 s of silence, file-global max clamp (whisper's transcribe():
+    log_mel_spectrogram(audio, n_mels, padding=N_SAMPLES)) on the GPU; recordings of equal length share a launch."""
+    import sys
+    from . import audio as wt_audio
+    from .naive import get_audio_tensor
+    dev = model.device
+    pcm = [get_audio_tensor(a).float().reshape(-1) for a in audios]
+    mels = [None] * len(pcm)
+    # the same choice backend.gpu_log_mel makes for the one-stream path: the HIP front end when it reproduces this
+    # backend's log_mel_spectrogram on a probe signal, else the backend's own function
+    theirs = getattr(sys.modules.get("whisper.transcribe"), "log_mel_spectrogram", None) or backend.whisper().log_mel_spectrogram
+    if not (efficient.GPU_FRONT_END and backend._front_end_matches(theirs, wt_audio, dev, model.dims.n_mels)):
+        return [theirs(p, model.dims.n_mels, padding=N_SAMPLES).to(dev).to(dtype) for p in pcm]
+    by_len = {}
+    for i, p in enumerate(pcm):
+        by_len.setdefault(int(p.numel()), []).append(i)
+    fb = wt_audio.mel_filters(dev, model.dims.n_mels)
+    for n, idx in by_len.items():
+        if n == 0:
+            for i in idx:
+                mels[i] = wt_audio.log_mel_spectrogram(pcm[i], n_mels=model.dims.n_mels, padding=N_SAMPLES, device=dev)
+            continue
+        batch = torch.zeros((len(idx), n + N_SAMPLES), dtype=torch.float32, device=dev)
+        for j, i in enumerate(idx):
+            batch[j, :n] = pcm[i].to(dev, non_blocking=True)
+        mel, _ = _lib.logmel(batch, fb, None, n_frames=(n + N_SAMPLES) // HOP_LENGTH)
+        for j, i in enumerate(idx):
+            mels[i] = mel[j]
+    return [m.to(dtype) for m in mels]
+
+
+def transcribe_efficient_streams(model, audios, *, remove_punctuation_from_words, compute_word_confidence,
+                                 include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
+                                 plot_word_alignment, word_alignment_most_top_layers, detect_disfluencies,
+                                 trust_whisper_timestamps, use_timestamps_for_alignment=True, max_streams=32,
+                                 **whisper_options):
+    """``[transcribe_efficient(model, a, ...) for a in audios]`` with the recordings decoded ``max_streams`` at a time.
+    Returns a list of (transcription, words), one per recording, in order."""
+    assert supports(whisper_options, plot_word_alignment=plot_word_alignment)
+    out = []
+    for a in range(0, len(audios), max_streams):
+        out.extend(_run_streams(model, audios[a:a + max_streams], dict(whisper_options),
+                                remove_punctuation_from_words=remove_punctuation_from_words,
+                                compute_word_confidence=compute_word_confidence,
+                                include_punctuation_in_confidence=include_punctuation_in_confidence,
+                                refine_whisper_precision_nframes=refine_whisper_precision_nframes,
+                                alignment_heads=alignment_heads, word_alignment_most_top_layers=word_alignment_most_top_layers,
+                                detect_disfluencies=detect_disfluencies, trust_whisper_timestamps=trust_whisper_timestamps,
+                                use_timestamps_for_alignment=use_timestamps_for_alignment))
+    return out
+
+
+def _run_streams(model, audios, opts, **session_kwargs):
+    w = backend.whisper()
+    dev = model.device
+    _lib.require_gpu(dev)
+    B = len(audios)
+    opts["verbose"] = None
+    fp16 = bool(opts.get("fp16"))
+    dtype = torch.float16 if fp16 else torch.float32
+    decode_keys = ("task", "language", "sample_len", "best_of", "beam_size", "patience", "length_penalty", "suppress_tokens",
+                   "fp16")                               # what whisper's transcribe() hands to DecodingOptions
+    temperature = opts["temperature"]
+
+    n_blocks = len(model.decoder.blocks)
+    top_layers = session_kwargs["word_alignment_most_top_layers"]
+    top = n_blocks if top_layers is None else min(top_layers, n_blocks)
+    hooked_blocks = list(range(n_blocks - top, n_blocks))
+    rings = StreamRings(model, session_kwargs["alignment_heads"], hooked_blocks, B, efficient.RING_DTYPE)
+    sink = _Sink(default_workspace(dev))
+    mels = _whole_file_mels(model, audios, dtype)
+
+    with torch.no_grad():
+        # ---- language (whisper's transcribe(): detect on the first 30 s when not given), one batched call
+        languages = [opts["language"]] * B
+        lang_events = None
+        if opts["language"] is None:
+            if not model.is_multilingual:
+                languages = ["en"] * B
+            else:
+                first = torch.stack([torch.nn.functional.pad(m[:, :N_FRAMES], (0, max(0, N_FRAMES - m.shape[-1]))) for m in mels])
+                rec = _Recorder(model, rings, hooked_blocks, torch.arange(B, dtype=torch.int32, device=dev), verify=False)
+                rec.capture = False
+                rec.install()
+                try:
+                    _, probs = model.detect_language(first)
+                finally:
+                    rec.remove()
+                languages = [max(p, key=p.get) for p in probs]
+                lang_events = (first, rec.calls[0], rec.first_outs, _lib.HostCopy(_lib.find_start_padding(first.float())))
+
+        streams = []
+        for i in range(B):
+            s_opts = dict(opts)
+            session = EfficientSession(model, s_opts, ring=_QKView(rings.qk[i]), logits=_LogitsView(rings.logits[i]), sink=sink,
+                                       **session_kwargs)
+            tk = backend.get_tokenizer(model, task=opts["task"], language=languages[i])
+            prompt0 = tk.encode(" " + opts["initial_prompt"].strip()) if opts.get("initial_prompt") is not None else []
+            streams.append(_Stream(i, mels[i], mels[i].shape[-1] - N_FRAMES, session, tk, languages[i], prompt0))
+        if lang_events is not None:                       # the language-detection call, as every stream's hooks saw it
+            first, calls, outs, pad0 = lang_events
+            for s in streams:
+                m = first[s.index:s.index + 1]
+                s.session.hook_mel(None, (m,), None, pad_handle=_SliceOfCopy(pad0, s.index))
+                s.session.on_tokens(list(calls[s.index]))
+                s.session.hook_decoder_logits(None, None, outs[s.index:s.index + 1])
+
+        rounds = groups = 0
+        verify = efficient.REUSE_DECODER_LOGITS == "auto"
+        fused_checked = False
+        while True:
+            act = [s for s in streams if s.active()]
+            if not act:
+                break
+            rounds += 1
+            # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
+            mel_batch = torch.stack([s.window_mel() for s in act]).to(dtype)
+            pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
+            for j, s in enumerate(act):
+                kwargs = {k: opts[k] for k in decode_keys if k in opts}
+                kwargs["language"] = s.language
+                kwargs["prompt"] = s.all_tokens[s.prompt_reset_since:]
+                if temperature > 0:
+                    kwargs.pop("beam_size", None), kwargs.pop("patience", None)
+                else:
+                    kwargs.pop("best_of", None)
+                s.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
+                s.initial_tokens = list(s.task.initial_tokens)
+                s.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
+                s.session.on_tokens(list(s.initial_tokens))
+            sink.launch()
+            # ---- one batched decoder loop per initial-token length
+            by_len = {}
+            for j, s in enumerate(act):
+                by_len.setdefault(len(s.initial_tokens), []).append(j)
+            for L, members in by_len.items():
+                groups += 1
+                grp = [act[j] for j in members]
+                if ON_GROUP_DECODE is not None:
+                    ON_GROUP_DECODE([s.index for s in grp])
+                task = grp[0].task
+                ring_index = torch.tensor([s.index for s in grp], dtype=torch.int32, device=dev)
+                rec = _Recorder(model, rings, hooked_blocks, ring_index, verify=verify)
+                rec.fused_checked = fused_checked or not efficient.FUSED_ATTENTION
+                task.decoder.reset()
+                rec.install()
+                try:
+                    feats = task._get_audio_features(mel_batch[members])
+                    tokens0 = torch.tensor([s.initial_tokens for s in grp], device=dev)
+                    tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
+                    rec.commit()
+                finally:
+                    rec.remove()
+                fused_checked = True
+                _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify)
+        for s in streams:
+            s.session.end_of_stream()
+        sink.resolve()
+        out = [s.session.compiled(s.transcription()) for s in streams]
+    LAST_RUN.clear()
+    LAST_RUN.update(streams=B, rounds=rounds, decoder_loops=groups, alignment_launch_sets=sink.launch_sets)
+    return out
+
+
+def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify):
+    """After a batched decoder loop: results per stream, the chosen-token log-probabilities of all streams in one launch,
+    the loop's recorded calls replayed into every stream's session, the backend's window bookkeeping."""
+    tk = task.tokenizer
+    g = len(grp)
+    L = task.sample_begin
+    tokens_f, sums = task.decoder.finalize(tokens.reshape(g, 1, -1), sum_logprobs.reshape(g, 1))
+    rows_host = tokens.tolist()
+    n_calls = len(rec.calls)
+    # each stream takes part in the calls up to the one whose sample was <|endoftext|> (later calls feed it eot)
+    sampled, results = [], []
+    for i, s in enumerate(grp):
+        t = tokens_f[i][0]
+        t = t.tolist() if hasattr(t, "tolist") else list(t)
+        body = t[L:]
+        cut = body.index(tk.eot) if tk.eot in body else len(body)
+        out_tokens = body[:cut]
+        lp = sums[i][0] if isinstance(sums[i], (list, tuple)) else sums[i]
+        results.append((out_tokens, float(lp) / (len(out_tokens) + 1)))
+        smp = rows_host[i][L:]                               # what the sampler returned at calls 0, 1, ...
+        n_mine = min(n_calls, (smp.index(tk.eot) + 1) if tk.eot in smp else len(smp))
+        sampled.append(smp[:n_mine])
+    # the sampler's in-place filtering must be there (<|notimestamps|> is always suppressed) -- one read for the group
+    idx = rec.ring_index_long
+    if tk.no_timestamps is not None:
+        if not bool(torch.isinf(rings.logits[idx, 0, tk.no_timestamps]).all()):
+            raise RuntimeError("streams: this backend does not filter the decoder's logits in place; use the one-stream path "
+                               "(whisper_timestamped.efficient.REUSE_DECODER_LOGITS = False)")
+    if verify and rec.verified is not None:
+        # "auto": the first token of the window both ways, for every stream (same -inf pattern, same values)
+        got, want = rec.verified
+        context = torch.tensor([s.initial_tokens for s in grp], device=got.device)
+        want = want.clone()
+        for f in task.logit_filters:
+            f.apply(want, context)
+        fin = torch.isfinite(want)
+        tol = 1e-3 if want.dtype == torch.float32 and not opts.get("fp16") else 5e-2
+        if not (bool(torch.equal(fin, torch.isfinite(got))) and bool(((got[fin] - want[fin]).abs() <= tol).all())):
+            raise RuntimeError("streams: the decoder's logits do not carry the sampler's filtering (or differ from the "
+                               "re-projected ones); use the one-stream path")
+    # ONE gather for every (stream, call): log_softmax(row)[sampled token]
+    cap1 = rings.logits.shape[1]
+    row_index = torch.tensor([int(s.index) * cap1 + k for i, s in enumerate(grp) for k in range(len(sampled[i]))], dtype=torch.int32)
+    tok = torch.tensor([t for smp in sampled for t in smp], dtype=torch.int32)
+    flat = rings.logits.view(-1, rings.logits.shape[-1])
+    lps = _lib.logprob_gather_rows(flat, row_index.to(flat.device), tok.to(flat.device)).cpu().numpy()
+    o = 0
+    for i, s in enumerate(grp):
+        n = len(sampled[i])
+        s.session.logits.known = (sampled[i], lps[o:o + n])
+        o += n
+    # replay: call 0 was the prompt (its token half ran before the loop); then the remaining calls of each stream
+    for i, s in enumerate(grp):
+        ses = s.session
+        assert rec.calls[0][i] == s.initial_tokens
+        ses.hook_decoder_logits(None, None, rec.first_outs[i:i + 1])
+        view = rings.logits[s.index]
+        for k in range(1, len(sampled[i])):
+            ses.on_tokens(rec.calls[k][i])
+            ses.hook_decoder_logits(None, None, view[k:k + 1].unsqueeze(0))
+        out_tokens, avg_logprob = results[i]
+        s.take_result(out_tokens, avg_logprob, float(no_speech[i]), temperature, opts, w)

@@ -133,9 +133,37 @@ def transcribe_timestamped(
     speech islands as ``vad=[(start, end), ...]``, which runs the reference's glue / back-conversion),
     ``plot_word_alignment`` (debug plots), and a HuggingFace ``transformers`` model object as ``model``.
     Module switches that trade exact reference arithmetic for speed are listed in INTEGRATION.md ("Switches")."""
+    plan = _plan(model, locals())
+    model, audio = plan["model"], audio
     if seed is not None:
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
+    vad, naive_approach = plan["vad"], plan["naive_approach"]
+    if vad is not None:
+        audio = get_audio_tensor(audio)
+        audio, vad_segments, convert_timestamps = remove_non_speech(audio, method=vad, sample_rate=SAMPLE_RATE,
+                                                                    plot=plot_word_alignment, avoid_empty_speech=True)
+    else:
+        vad_segments = convert_timestamps = None
+
+    if naive_approach:
+        transcription, words = transcribe_naive(model, audio, min_word_duration=0.0,
+                                                trust_whisper_timestamps=trust_whisper_timestamps,
+                                                use_backend_timestamps=use_backend_timestamps,
+                                                **plan["alignment_options"], **plan["whisper_options"], **plan["other_options"])
+    else:
+        transcription, words = transcribe_efficient(model, audio, trust_whisper_timestamps=trust_whisper_timestamps,
+                                                    **plan["alignment_options"], **plan["whisper_options"],
+                                                    **plan["other_options"])
+    return _assemble(transcription, words, plan, vad_segments, convert_timestamps)
+
+
+def _plan(model, a):
+    """Option checks, strategy selection and the option dictionaries of T.py:221-296, from the caller's arguments `a`."""
+    refine_whisper_precision, min_word_duration = a["refine_whisper_precision"], a["min_word_duration"]
+    word_alignment_most_top_layers = a["word_alignment_most_top_layers"]
+    temperature, best_of, beam_size = a["temperature"], a["best_of"], a["beam_size"]
+    naive_approach, verbose = a["naive_approach"], a["verbose"]
 
     steps = refine_whisper_precision / AUDIO_TIME_PER_TOKEN
     assert refine_whisper_precision >= 0 and steps == round(steps), \
@@ -153,12 +181,13 @@ def transcribe_timestamped(
         naive_approach = True
     if beam_size is not None:                                   # beam search
         naive_approach = True
-    if is_transformer_model(model) or use_backend_timestamps:
+    if is_transformer_model(model) or a["use_backend_timestamps"]:
         naive_approach = True
 
-    vad = check_vad_method(vad)
+    vad = check_vad_method(a["vad"])
     if isinstance(model, str):
         model = load_model(model)
+    fp16 = a["fp16"]
     if fp16 is None:
         fp16 = model.device != torch.device("cpu")
 
@@ -170,38 +199,32 @@ def transcribe_timestamped(
         word_alignment_most_top_layers = 6
 
     alignment_options = dict(
-        remove_punctuation_from_words=remove_punctuation_from_words, compute_word_confidence=compute_word_confidence,
-        include_punctuation_in_confidence=include_punctuation_in_confidence, detect_disfluencies=detect_disfluencies,
-        refine_whisper_precision_nframes=refine_nframes, plot_word_alignment=plot_word_alignment,
+        remove_punctuation_from_words=a["remove_punctuation_from_words"], compute_word_confidence=a["compute_word_confidence"],
+        include_punctuation_in_confidence=a["include_punctuation_in_confidence"], detect_disfluencies=a["detect_disfluencies"],
+        refine_whisper_precision_nframes=refine_nframes, plot_word_alignment=a["plot_word_alignment"],
         word_alignment_most_top_layers=word_alignment_most_top_layers, alignment_heads=alignment_heads)
     whisper_options = dict(
-        language=language, task=task, fp16=fp16, temperature=temperature, best_of=best_of, beam_size=beam_size,
-        patience=patience, length_penalty=length_penalty, condition_on_previous_text=condition_on_previous_text,
-        initial_prompt=initial_prompt, suppress_tokens=suppress_tokens, sample_len=sample_len,
+        language=a["language"], task=a["task"], fp16=fp16, temperature=temperature, best_of=best_of, beam_size=beam_size,
+        patience=a["patience"], length_penalty=a["length_penalty"], condition_on_previous_text=a["condition_on_previous_text"],
+        initial_prompt=a["initial_prompt"], suppress_tokens=a["suppress_tokens"], sample_len=a["sample_len"],
         verbose=verbose if (not vad or verbose is not True) else False,
     )
-    other_options = dict(no_speech_threshold=no_speech_threshold, logprob_threshold=logprob_threshold,
-                         compression_ratio_threshold=compression_ratio_threshold)
+    other_options = dict(no_speech_threshold=a["no_speech_threshold"], logprob_threshold=a["logprob_threshold"],
+                         compression_ratio_threshold=a["compression_ratio_threshold"])
+    return dict(model=model, vad=vad, naive_approach=naive_approach, alignment_options=alignment_options,
+                whisper_options=whisper_options, other_options=other_options, verbose=verbose,
+                refine_whisper_precision=refine_whisper_precision, min_word_duration=min_word_duration,
+                remove_empty_words=a["remove_empty_words"], trust_whisper_timestamps=a["trust_whisper_timestamps"])
 
-    if vad is not None:
-        audio = get_audio_tensor(audio)
-        audio, vad_segments, convert_timestamps = remove_non_speech(audio, method=vad, sample_rate=SAMPLE_RATE,
-                                                                    plot=plot_word_alignment, avoid_empty_speech=True)
-    else:
-        vad_segments = None
 
-    if naive_approach:
-        transcription, words = transcribe_naive(model, audio, min_word_duration=0.0,
-                                                trust_whisper_timestamps=trust_whisper_timestamps,
-                                                use_backend_timestamps=use_backend_timestamps,
-                                                **alignment_options, **whisper_options, **other_options)
-    else:
-        transcription, words = transcribe_efficient(model, audio, trust_whisper_timestamps=trust_whisper_timestamps,
-                                                    **alignment_options, **whisper_options, **other_options)
-    if remove_empty_words:
+def _assemble(transcription, words, plan, vad_segments=None, convert_timestamps=None):
+    """(transcription, words) of a strategy -> the public result dictionary (T.py:313-357)."""
+    verbose, vad, naive_approach = plan["verbose"], plan["vad"], plan["naive_approach"]
+    refine_whisper_precision = plan["refine_whisper_precision"]
+    if plan["remove_empty_words"]:
         transcription, words = remove_last_null_duration_words(transcription, words, recompute_text=True)
 
-    ensure_increasing_positions(words, min_duration=min_word_duration if trust_whisper_timestamps else 0)
+    ensure_increasing_positions(words, min_duration=plan["min_word_duration"] if plan["trust_whisper_timestamps"] else 0)
 
     segments = transcription["segments"]
     for word in words:
@@ -236,6 +259,33 @@ def transcribe_timestamped(
     if vad_segments is not None:
         transcription["speech_activity"] = [{"start": s, "end": e} for (s, e) in vad_segments]
     return transcription
+
+
+def transcribe_batch(model, audios, max_streams=32, **options):
+    """``[transcribe_timestamped(model, a, **options) for a in audios]`` for INDEPENDENT recordings, with up to
+    ``max_streams`` of them stepping through the decoder together (streams.py).  Not in the reference, whose efficient
+    strategy decodes one stream (T.py:806): same options, same result dictionaries, one per recording.  Calls the B-stream
+    path cannot take (naive strategy: beam search / temperature fallback / best_of; ``vad``) run one recording at a time."""
+    import inspect
+    sig = inspect.signature(transcribe_timestamped)
+    unknown = set(options) - set(sig.parameters)
+    assert not unknown, f"transcribe_batch: unknown options {sorted(unknown)}"
+    a = {k: p.default for k, p in sig.parameters.items() if p.default is not inspect.Parameter.empty}
+    a.update(options)
+    audios = list(audios)
+    if not audios:
+        return []
+    plan = _plan(model, a)
+    from . import streams
+    if not streams.supports(plan["whisper_options"], plan["vad"], plan["naive_approach"], a["plot_word_alignment"]):
+        return [transcribe_timestamped(model, audio, **options) for audio in audios]
+    if a["seed"] is not None:
+        torch.manual_seed(a["seed"])
+        torch.cuda.manual_seed_all(a["seed"])
+    pairs = streams.transcribe_efficient_streams(plan["model"], audios, trust_whisper_timestamps=a["trust_whisper_timestamps"],
+                                                 max_streams=max_streams, **plan["alignment_options"],
+                                                 **plan["whisper_options"], **plan["other_options"])
+    return [_assemble(t, w, plan) for t, w in pairs]
 
 
 transcribe = transcribe_timestamped
