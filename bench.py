@@ -1155,29 +1155,36 @@ def run_efficient_leg(args, emit):
             efficient.REUSE_DECODER_LOGITS = False         # a second projection + filters per token (T.py:871-874)
             efficient.DEFER_ALIGNMENT = False              # one synchronous alignment per segment (T.py:544-557)
             model_cpu = H.load_base("cpu")
-            done, t0, worst_t = 0, time.perf_counter(), 0.0
-            while done < len(clips):
+            all_threads = torch.get_num_threads()
+            runs, worst_t = [], 0.0
+            # token-by-token decoding is a chain of small GEMVs: all cores of the box are not the fastest setting, so
+            # the baseline is taken at the better of two thread counts (both reported)
+            for k, threads in enumerate((min(16, all_threads), all_threads)):
+                torch.set_num_threads(threads)
                 set_script(Script([window]))
+                t0 = time.perf_counter()
                 try:
-                    r = wt.transcribe(model_cpu, clips[done], language="en", fp16=False)
+                    r = wt.transcribe(model_cpu, clips[k], language="en", fp16=False)
                 finally:
                     set_script(None)
-                a, b = words_of(r), words_of(singles[done])
+                    torch.set_num_threads(all_threads)
+                runs.append({"threads": threads, "seconds_per_clip": round(time.perf_counter() - t0, 2)})
+                a, b = words_of(r), words_of(singles[k])
                 assert [x[0] for x in a] == [x[0] for x in b], "GPU and CPU words differ"
                 worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
-                done += 1
-                if time.perf_counter() - t0 > args.e2e_cpu_budget:
+                if threads == all_threads:
                     break
-            el = time.perf_counter() - t0
+            best = min(runs, key=lambda x: x["seconds_per_clip"])
+            done = len(runs)
         finally:
             patch.undo()
             for k, v in saved.items():
                 setattr(efficient, k, v)
-        out["cpu_baseline"] = {"value": round(30.0 * done / el, 2), "unit": "audio-seconds/s", "cores": int(torch.get_num_threads()),
-                               "kind": "port",
-                               "sample": f"{done} of the same clips, one stream: the same whisper-base on the CPU, unfused attention "
-                                         f"with per-token QK capture, second projection + logit filters per token, one alignment "
-                                         f"per segment through oracle/, {el:.1f} s wall"}
+        out["cpu_baseline"] = {"value": round(30.0 / best["seconds_per_clip"], 2), "unit": "audio-seconds/s", "cores": best["threads"],
+                               "kind": "port", "runs": runs,
+                               "sample": f"one 30 s clip per thread setting (the faster one is the baseline), one stream: the same "
+                                         f"whisper-base on the CPU, unfused attention with per-token QK capture, second projection "
+                                         f"+ logit filters per token, one alignment per segment through oracle/"}
         out["parity_vs_cpu_reference_path"] = {"clips": done, "max_abs_dt_word_s": round(worst_t, 4)}
         out["speedup_vs_cpu"] = {"1_stream": round(out["1_stream"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1),
                                  f"{B}_streams": round(out[f"{B}_streams"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)}
