@@ -209,33 +209,6 @@ def test_transcribe_with_the_reference_attention_path(monkeypatch):
         _report(name + "[unfused attention]", dt, dc)
 
 
-def test_batched_forward_as_hip_graph_equals_eager():
-    """BatchedAligner(forward_graph=True): the model's forward pass replayed as one captured HIP graph per shape -- same
-    words, same times, same log-probabilities as the eager pass (two replays of the same graph included)."""
-    import numpy as np
-    import whisper_double as W
-    W.install()
-    from whisper_timestamped.batched import BatchedAligner, WindowJob, align_windows
-    model = W.build_model("tiny", seed=0, device="cuda:0")
-    tk = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
-    g = torch.Generator().manual_seed(7)
-    ts0 = tk.timestamp_begin
-    jobs = []
-    for k in range(5):
-        pcm = (torch.randn(int((20 + 2 * k) * 16000), generator=g) * 0.1).to("cuda:0")
-        toks = [ts0 + 5] + G.text_ids(200 + k, 9 + k) + [ts0 + 400, ts0 + 420] + G.text_ids(300 + k, 6) + [ts0 + 900]
-        jobs.append(WindowJob(pcm, toks, pcm.numel(), tag=k))
-    out = {}
-    for graph in (False, True):
-        aligner = BatchedAligner(model, tk, language="en", forward_graph=graph)
-        out[graph] = [list(align_windows(aligner, jobs, 5)) for _ in range(2)]
-    for eager, replay in zip(out[False][0] * 2, out[True][0] + out[True][1]):
-        assert [w["text"] for w in eager.words] == [w["text"] for w in replay.words]
-        assert [(w["start"], w["end"]) for w in eager.words] == [(w["start"], w["end"]) for w in replay.words]
-        for a, b in zip(eager.word_logprobs, replay.word_logprobs):
-            assert np.allclose(a.numpy(), b.numpy(), rtol=0, atol=1e-5)
-
-
 @pytest.mark.parametrize("name,heads", [("small", "table"), ("tiny-v3", None)])
 def test_batched_aligner_whole_batch_equals_one_window_at_a_time(name, heads):
     """Other model shapes through the batched kernels: whisper-small dims (12 heads of 64, the 10 table heads spread over

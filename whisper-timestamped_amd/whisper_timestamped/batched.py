@@ -80,7 +80,7 @@ class BatchedAligner:
                  word_alignment_most_top_layers=None, refine_whisper_precision_nframes=25,
                  remove_punctuation_from_words=False, compute_word_confidence=True,
                  include_punctuation_in_confidence=False, detect_disfluencies=False, ring_dtype=torch.float32,
-                 mel_dtype=None, fused_attention=None, forward_graph=False):
+                 mel_dtype=None, fused_attention=None):
         from . import efficient
         self.model, self.tk = model, tokenizer
         self.dev = model.device
@@ -110,11 +110,9 @@ class BatchedAligner:
         self.n_mels = model.dims.n_mels if hasattr(model.dims, "n_mels") else 80
         self.workspace = default_workspace(self.dev)
         self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
-        # Opt-in: replay the model's forward pass (encoder + teacher-forced decoder, ~300 small launches whose Python
-        # dispatch costs more than their GPU time once the model runs in half precision) as ONE captured HIP graph per
-        # (windows, padded length) shape.  The alignment kernels stay outside the graph.
-        self.forward_graph = bool(forward_graph) and self.fused
-        self._graphs = {}
+        # (Rounds 2-3 carried an opt-in replay of the forward pass as one captured HIP graph per shape.  Since round 3 the
+        #  eager half-precision pass is GPU-bound -- 96 % busy in its own process -- so a replay could gain 4 % at most, and
+        #  it measured 1.4-2x SLOWER, 33-48 k against 66 k audio-s/s: removed in round 4)
         sot = tokenizer.sot_sequence
         if language and len(sot) == 3:                                   # :1230-1232
             sot = (sot[0], tokenizer.to_language_token(language), sot[2])
@@ -169,32 +167,6 @@ class BatchedAligner:
                 h.remove()
         return logits, q_out, k_out, captured
 
-    def _forward_replayed(self, x, tok_dev):
-        """The same through a HIP graph captured once per shape (static input / output buffers owned by the graph)."""
-        key = (tuple(x.shape), x.dtype, tuple(tok_dev.shape))
-        g = self._graphs.get(key)
-        if g is None:
-            if len(self._graphs) >= 4:                       # a few shapes at most: each graph keeps its own buffers
-                self._graphs.pop(next(iter(self._graphs)))
-            sx, st_ = torch.empty_like(x), torch.empty_like(tok_dev)
-            sx.copy_(x)
-            st_.copy_(tok_dev)
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(side):                    # warm-up outside the capture (GEMM plans, allocator)
-                for _ in range(2):
-                    self._forward(sx, st_)
-            torch.cuda.current_stream(self.dev).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                outs = self._forward(sx, st_)
-            g = self._graphs[key] = (graph, sx, st_, outs)
-        graph, sx, st_, outs = g
-        sx.copy_(x)
-        st_.copy_(tok_dev)
-        graph.replay()
-        return outs
-
     # ------------------------------------------------------------------ device: one sub-batch, nothing waits
     def launch(self, jobs) -> _Stage:
         tk, dev = self.tk, self.dev
@@ -230,7 +202,7 @@ class BatchedAligner:
             self._mark(st, "model<")
             # encoder + teacher-forced decoder on the whole batch (:1236-1238); no logit filters on this path (:1245)
             x = mel if self.mel_dtype is None else mel.to(self.mel_dtype)
-            logits, q_out, k_out, captured = (self._forward_replayed if self.forward_graph else self._forward)(x, tok_dev)
+            logits, q_out, k_out, captured = self._forward(x, tok_dev)
             self._mark(st, "model>")
             self._mark(st, "qk_rows<")
             # the alignment heads' QK rows of every window: (B, A, T_max, 1500)
