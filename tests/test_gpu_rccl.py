@@ -20,34 +20,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(rank, world, port):
+def _setup(rank, world, port, gpu=0):
     for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    torch.cuda.set_device(gpu)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu))
     return dist
 
 
-def _one_rank_worker(rank, world, port, out_path):
+def _one_rank_worker(rank, world, port, out_path, gpu_per_rank=False):
+    """world = 1, or 2 ranks: both on cuda:0 (the one-GPU box, if RCCL allows it) or -- gpu_per_rank -- rank r on cuda:r."""
     import numpy as np
-    dist = _setup(rank, world, port)
+    gpu = rank if gpu_per_rank else 0
+    dist = _setup(rank, world, port, gpu)
     from whisper_timestamped.sharding import ResultGatherer, broadcast_module_weights, partition_units
-    dev = torch.device("cuda", 0)
-    report = {"backend": dist.get_backend(), "world": world}
+    dev = torch.device("cuda", gpu)
+    report = {"backend": dist.get_backend(), "world": world, "gpus": sorted({0, gpu}) if not gpu_per_rank else list(range(world))}
     try:
-        # 1. flat weight broadcast (one message per dtype) through RCCL
+        # 1. flat weight broadcast (one message per dtype) through RCCL: every other rank starts from OTHER weights
         import whisper_double as W
-        model = W.build_model("tiny", seed=0, device=dev)
-        before = [p.detach().clone() for p in model.parameters()]
+        model = W.build_model("tiny", seed=0 if rank == 0 else 100 + rank, device=dev)
+        want = [p.detach().clone() for p in W.build_model("tiny", seed=0, device=dev).parameters()]
+        if rank != 0:
+            assert not all(torch.equal(a, b) for a, b in zip(model.parameters(), want))
         t0 = time.perf_counter()
         broadcast_module_weights(dist, model, src=0)
         torch.cuda.synchronize()
         report["broadcast_weights_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         report["broadcast_bytes"] = int(sum(p.numel() * p.element_size() for p in model.parameters()))
-        for a, b in zip(model.parameters(), before):
+        for a, b in zip(model.parameters(), want):
             assert torch.equal(a, b)
 
         # 2. result records: asynchronous, double buffered, 8 steps per message
@@ -74,19 +78,22 @@ def _one_rank_worker(rank, world, port, out_path):
         torch.cuda.synchronize()
         report["gather_19_steps_every_8_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
         report["gather_message_bytes"] = int(8 * (cap_j + cap_l) * 4)
-        bj, bl = g.unpack(0, step=0)
-        oj = ol = 0
-        for i in parts[0]:
-            T, F = units[i]
-            j, lp = _jumps_for(i, T, F)
-            assert np.array_equal(bj[oj:oj + T + 1].cpu().numpy(), j) and np.array_equal(bl[ol:ol + T].cpu().numpy(), lp)
-            oj += T + 1
-            ol += T
+        if rank == 0:                                            # the last message: every rank's records, verified
+            for r in range(world):
+                bj, bl = g.unpack(r, step=0)
+                oj = ol = 0
+                for i in parts[r]:
+                    T, F = units[i]
+                    j, lp = _jumps_for(i, T, F)
+                    assert np.array_equal(bj[oj:oj + T + 1].cpu().numpy(), j) and np.array_equal(bl[ol:ol + T].cpu().numpy(), lp), (r, i)
+                    oj += T + 1
+                    ol += T
+            report["gather_records_verified_for_ranks"] = list(range(world))
 
         # 3. the long-form island job with dist=... (weights broadcast, audio shared, results gathered)
         job = _islands_job()
         t0 = time.perf_counter()
-        result, seen = _run_islands_job(dist, job, None, device="cuda:0")
+        result, seen = _run_islands_job(dist, job, None, device=f"cuda:{gpu}")
         report["islands_job_s"] = round(time.perf_counter() - t0, 3)
         if rank == 0:
             assert sorted(seen) == ([0, 1, 2, 3] if world == 1 else sorted(seen))
@@ -191,3 +198,44 @@ def test_islands_job_two_ranks_on_one_gpu_if_rccl_allows(tmp_path):
     report = json.loads(out.read_text())
     assert report["world"] == 2 and all(len(p) > 0 for p in report["islands_per_rank"])
     _keep(report, "rccl_two_ranks.json")
+
+
+# ---------------------------------------------------------------------------------------------------- two (or more) GPUs
+# The gpurun box has one GPU and the driver's 8-GPU node is not ours to launch on: these run wherever >= 2 GPUs are
+# visible (and skip, saying so, elsewhere), so that the first multi-GPU run is a measurement, not a debugging session.
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs (one rank per GPU over RCCL)")
+
+
+@needs_two_gpus
+@pytest.mark.timeout(900)
+def test_sharding_layer_two_ranks_two_gpus_over_rccl(tmp_path):
+    """rank r on cuda:r: the flat weight broadcast (rank 1 starts from other weights), the asynchronous double-buffered
+    ResultGatherer with EVERY rank's records verified on rank 0, and transcribe_islands on two ranks against
+    tests/golden/islands_job.json (the reference's own per-island output)."""
+    out = tmp_path / "rccl2gpu.json"
+    mp.spawn(_one_rank_worker, args=(2, _free_port(), str(out), True), nprocs=2, join=True)
+    report = json.loads(out.read_text())
+    assert report["backend"] == "nccl" and report["world"] == 2 and report["gather_records_verified_for_ranks"] == [0, 1]
+    assert report["islands_max_abs_dt_s"] <= 0.02 and all(len(p) > 0 for p in report["islands_per_rank"])
+    _keep(report, "rccl_two_ranks_two_gpus.json")
+
+
+@needs_two_gpus
+@pytest.mark.timeout(900)
+def test_bench_two_gpus_prints_one_line_with_two_rccl_ranks():
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` (the driver's form for N = 2): it launches itself under
+    torch.distributed.run, one rank per GPU; the line must parse, carry rccl_ranks_seen = 2 and the per-rank times."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert len(d["per_rank"]["ms_per_step"]) == 2 and "share_of_step" in d["result_gather"]
+    assert d["parity_in_leg"]["ok"] and d["cpu_baseline"] == "N=1 line only" and d["roofline"]["frac"] > 0
+    _keep(d, "bench_two_gpus.json")
