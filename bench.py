@@ -269,10 +269,11 @@ def make_workload_kreal(dev, cfg, seed):
                 stairs=stairs)
 
 
-STAGES = ["logmel", "padding", "cost", "dtw", "logprob"]
+# (round 4: the padding detector is part of the log-mel stage -- wt_logmel_pad_batch decides find_start_padding in the
+#  pass that finalises the windows; rounds 1-3 timed a separate "padding" stage of one launch)
+STAGES = ["logmel", "cost", "dtw", "logprob"]
 # kernels of each stage as rocprofv3 names them (profiles/*traffic.json keys)
-STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel"],
-                 "padding": ["find_start_padding_kernel"], "cost": ["rowmean_kernel", "colnorm_kernel", "fix00_kernel"],
+STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel"], "cost": ["rowmean_kernel", "colnorm_kernel", "fix00_kernel"],
                  "dtw": ["dtw_kernel"], "logprob": ["logprob_gather_kernel"]}
 
 
@@ -306,12 +307,9 @@ def _stage_calls(w):
     n_rows = cfg.get("n_rows") or n * cfg["T"]
 
     def logmel(st):
-        _lib._check(L.wt_logmel_batch(w["pcm"].data_ptr(), n, 480000, w["n_valid"].data_ptr(), w["fb"].data_ptr(), cfg["n_mels"], 3000,
-                                      w["mel"].data_ptr(), w["gmax"].data_ptr(), st), "wt_logmel_batch")
-
-    def padding(st):
-        _lib._check(L.wt_find_start_padding_batch(w["mel"].data_ptr(), n, cfg["n_mels"], 3000, w["pad"].data_ptr(), st),
-                    "wt_find_start_padding_batch")
+        _lib._check(L.wt_logmel_pad_batch(w["pcm"].data_ptr(), n, 480000, w["n_valid"].data_ptr(), w["fb"].data_ptr(), cfg["n_mels"],
+                                          3000, w["mel"].data_ptr(), w["gmax"].data_ptr(), w["pad"].data_ptr(), st),
+                    "wt_logmel_pad_batch")
 
     def cost(st):
         _lib._check(L.wt_cost_batch(w["qk"].data_ptr(), 1 if cfg.get("qk_dtype") == "f16" else 0, w["descs"].ctypes.data, w["descs_dev"].data_ptr(), n_units,
@@ -337,11 +335,11 @@ def _stage_calls(w):
         _lib._check(L.wt_logprob_gather_batch(w["logits"].data_ptr(), 0, V, n_rows, V, w["tokens"].data_ptr(), 0, 0,
                                               w["logprob"].data_ptr(), st), "wt_logprob_gather_batch")
 
-    return dict(logmel=logmel, padding=padding, cost=cost, dtw=dtw, logprob=logprob)
+    return dict(logmel=logmel, cost=cost, dtw=dtw, logprob=logprob)
 
 
 # stage -> lane: with --overlap the three lanes run on three HIP streams (the stages of one lane stay ordered)
-LANES = [["logmel", "padding"], ["cost", "dtw"], ["logprob"]]
+LANES = [["logmel"], ["cost", "dtw"], ["logprob"]]
 
 
 def cu_masked_streams(dev, n_dtw_cus):
@@ -379,7 +377,7 @@ def run_step(w, ev=None, streams=None):
         if ev: ev["dtw"][0].record(side)
         calls["dtw"](side.cuda_stream)
         if ev: ev["dtw"][1].record(side)
-        for stage in ("logmel", "padding"):
+        for stage in ("logmel",):
             if ev: ev[stage][0].record(main)
             calls[stage](main.cuda_stream)
             if ev: ev[stage][1].record(main)
@@ -392,7 +390,7 @@ def run_step(w, ev=None, streams=None):
         # the HBM-bound log-prob gather on the other CUs: CU-masked streams, so neither kernel's waves land on the
         # other's CUs (without masks the gather's waves share the DTW's SIMDs and both kernels slow down)
         dtw_s, lp_s = streams[1], streams[2]
-        for stage in ("logmel", "padding", "cost"):
+        for stage in ("logmel", "cost"):
             if ev: ev[stage][0].record(main)
             calls[stage](main.cuda_stream)
             if ev: ev[stage][1].record(main)
@@ -408,7 +406,7 @@ def run_step(w, ev=None, streams=None):
         main.wait_stream(lp_s)
     elif isinstance(streams, tuple) and streams[0] == "dtw":
         side = streams[1]
-        for stage in ("logmel", "padding", "cost"):
+        for stage in ("logmel", "cost"):
             if ev: ev[stage][0].record(main)
             calls[stage](main.cuda_stream)
             if ev: ev[stage][1].record(main)
@@ -449,15 +447,13 @@ def algorithmic_bytes(cfg, fused=False):
     tf = sum(t * f for t, f in units)
     rows = sum(t for t, _ in units)
     n_valid = cfg.get("n_valid") or [480000] * n
-    logmel = sum(v * 4 for v in n_valid) + n * M * 3000 * 4        # the real samples in, the whole (M, 3000) window out
-    # an unpadded window is decided by its last column; a padded one by its zero columns and the first non-zero one
-    padding = sum(M * 4 * (1 if v >= 480000 else (3000 - v // 160 + 1)) for v in n_valid)
+    # the real samples in, the whole (M, 3000) window out, one padding index per window (decided while writing it)
+    logmel = sum(v * 4 for v in n_valid) + n * M * 3000 * 4 + n * 4
     if fused:   # the same bytes as the two stages below, moved by one entry point and timed as one stage
-        return {"logmel": logmel, "padding": padding,
+        return {"logmel": logmel,
                 "cost": A * tf * s_in + 2 * tf * 4 + 4 * (rows + len(units)), "dtw": 0, "logprob": rows * (V * 4 + 8)}
     return {
         "logmel": logmel,
-        "padding": padding,
         "cost": A * tf * s_in + tf * 4,                    # selected-head logits once, cost once
         "dtw": tf * 4 + 4 * (rows + len(units)),           # read cost once, write jumps
         "logprob": rows * (V * 4 + 8),                     # read each logit row once

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define WT_ABI_VERSION 4 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3;
-                            4: + wt_release_stream, wt_qk_rows_streams; only the WT_API entries are exported (the library is built with
+                            4: + wt_release_stream, wt_qk_rows_streams, wt_logmel_pad_batch; only the WT_API entries are exported (the library is built with
                                -fvisibility=hidden) */
 
 /* The exported surface: exactly the functions marked WT_API below (tests/test_host_cpu.py holds `nm -D` to it). */
@@ -245,6 +245,16 @@ WT_API int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t 
  * torch.stft-based log_mel_spectrogram to 2e-4 absolute (tests/test_gpu_parity.py). */
 WT_API int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
                     int n_mels, int n_frames, float *mel_out, float *gmax, void *stream);
+
+/* wt_logmel_batch + wt_find_start_padding_batch of the finished windows in the same two launches: the pass that
+ * finalises the log-mel (clamp at max - 8, (x + 4) / 4, zeros behind the valid frames) already streams every value
+ * it writes, so it also decides T.py:1795-1805 on those values -- start_of_padding[b] (device int32[n_chunks]) = -1
+ * (None: the last column is not all-zero), else the index after the last column in [1, n_frames - 2] that is not
+ * all-zero, else 0.  Identical to wt_find_start_padding_batch(mel_out, ...) run afterwards, without re-reading
+ * mel_out and without the detector's launch.  Meaningful for windows (n_frames = 3000), defined for any n_frames. */
+WT_API int wt_logmel_pad_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples,
+                               const float *mel_fb, int n_mels, int n_frames, float *mel_out, float *gmax,
+                               int32_t *start_of_padding, void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,7 @@ def install(monkeypatch):
         return torch.tensor(out, dtype=torch.int32)
     monkeypatch.setattr(_lib, "find_start_padding", find_start_padding)
 
-    def logmel(pcm, mel_fb, n_valid_samples=None, n_frames=3000):
+    def logmel(pcm, mel_fb, n_valid_samples=None, n_frames=3000, with_padding=False):
         B = pcm.shape[0]
         M = mel_fb.shape[0]
         mel = torch.zeros((B, M, n_frames))
@@ -49,6 +49,8 @@ def install(monkeypatch):
             m = O.log_mel_spectrogram_ref(pcm[b, :n], M)
             k = min(m.shape[-1], n_frames)
             mel[b, :, :k] = m[:, :k]
+        if with_padding:
+            return mel, gmax, find_start_padding(mel)
         return mel, gmax
     monkeypatch.setattr(_lib, "logmel", logmel)
 

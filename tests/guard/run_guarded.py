@@ -69,7 +69,7 @@ def guarded(t: torch.Tensor, mode: str) -> torch.Tensor:
 def guard_workload(w, mode):
     out = dict(w)
     out.pop("_calls", None)
-    for k in ("qk", "logits", "tokens", "pcm", "fb", "descs_dev", "head_idx", "cost", "mel", "gmax", "pad", "result"):
+    for k in ("qk", "logits", "tokens", "pcm", "n_valid", "fb", "descs_dev", "head_idx", "cost", "mel", "gmax", "pad", "result"):
         out[k] = guarded(w[k], mode)
     n_jumps = w["jumps"].numel()
     out["jumps"] = out["result"][:n_jumps]
@@ -214,12 +214,19 @@ def case_logmel(mode):
         mel = guarded(torch.zeros((B, n_mels, n_frames), device=dev), mode)
         gmax = guarded(torch.zeros(B, device=dev), mode)
         pad = guarded(torch.zeros(B, dtype=torch.int32, device=dev), mode)
+        pad2 = guarded(torch.full((B,), 77, dtype=torch.int32, device=dev), mode)
         for _ in range(2):
             L._check(L.load().wt_logmel_batch(gp.data_ptr(), B, N, L._ptr(gn), gf.data_ptr(), n_mels, n_frames, mel.data_ptr(),
                                               gmax.data_ptr(), st), "wt_logmel_batch")
             L._check(L.load().wt_find_start_padding_batch(mel.data_ptr(), B, n_mels, n_frames, pad.data_ptr(), st), "padding")
         torch.cuda.synchronize()
         assert torch.equal(mel, want) and torch.equal(gmax, want_max) and torch.equal(pad, want_pad), (B, N, n_mels, n_frames)
+        mel.zero_()
+        for _ in range(2):                 # the same with the detector folded into the finalising pass
+            L._check(L.load().wt_logmel_pad_batch(gp.data_ptr(), B, N, L._ptr(gn), gf.data_ptr(), n_mels, n_frames, mel.data_ptr(),
+                                                  gmax.data_ptr(), pad2.data_ptr(), st), "wt_logmel_pad_batch")
+        torch.cuda.synchronize()
+        assert torch.equal(mel, want) and torch.equal(gmax, want_max) and torch.equal(pad2, want_pad), (B, N, n_mels, n_frames, pad2, want_pad)
 
 
 def case_capture(mode):

@@ -645,6 +645,39 @@ def test_logmel_vs_oracle():
         assert L.find_start_padding(mel.to(DEV)).cpu().tolist()[2] == valid[2] // 160
 
 
+def test_logmel_pad_batch_equals_the_detector_run_afterwards():
+    """wt_logmel_pad_batch: find_start_padding decided by the pass that finalises the windows (transcribe.py:1795-1805 on
+    the VALUES it writes) == wt_find_start_padding_batch on the finished windows == the oracle's walk, for full windows
+    (None), ragged ones, tile-boundary and nearly empty ones, a silent one, 80 and 128 mel bins, window sizes that take
+    the 16-byte and the scalar path of the pass -- and the mel / max it returns are those of wt_logmel_batch."""
+    L = _lib()
+    rng = np.random.RandomState(23)
+    n = 480000
+    lengths = [n, 16000 * 7 + 77, 160 * 12 * 100, 201, n - 1, 160 * 2998, 160 * 2999, 160 * 3, n, 16000 * 29 + 159, 399, 160]
+    pcm = (0.1 * rng.standard_normal((len(lengths), n))).astype(np.float32)
+    for b, m in enumerate(lengths):
+        pcm[b, m:] = 0.0
+    pcm[8, :] = 0.0                                       # a full-length window of digital silence (no padding: None)
+    valid = torch.tensor(lengths, dtype=torch.int32)
+    for n_mels, n_frames in ((80, 3000), (128, 3000), (80, 2999), (80, 1501)):
+        fb = O.mel_filters_ref(n_mels)
+        mel0, gmax0 = L.logmel(torch.from_numpy(pcm).to(DEV), fb, valid, n_frames=n_frames)
+        mel1, gmax1, pad = L.logmel(torch.from_numpy(pcm).to(DEV), fb, valid, n_frames=n_frames, with_padding=True)
+        assert torch.equal(mel0, mel1) and torch.equal(gmax0, gmax1)
+        want = L.find_start_padding(mel0).cpu().tolist()
+        assert pad.cpu().tolist() == want, (n_mels, n_frames, pad.cpu().tolist(), want)
+        for b in range(len(lengths)):
+            r = O.find_start_padding_ref(mel0[b:b + 1].cpu())
+            assert want[b] == (-1 if r is None else int(r)), (n_mels, n_frames, b)
+        if n_frames == 3000:
+            assert want[0] == -1 and want[8] == -1 and want[1] == lengths[1] // 160 and want[3] == 0 and want[11] == 0 and want[7] == 3
+    # no valid samples argument at all: every window is full -> None everywhere; twice on the same stream (the per-chunk
+    # word the votes merge into is re-zeroed by every call)
+    for _ in range(2):
+        _, _, pad = L.logmel(torch.from_numpy(pcm[:3]).to(DEV), O.mel_filters_ref(80), None, with_padding=True)
+        assert pad.cpu().tolist() == [-1, -1, -1]
+
+
 def test_logmel_batch_walks_tiles():
     """The STFT kernel is persistent: with more tiles than resident workgroups (4 per CU) a workgroup walks several
     tiles, prefetching the next span while it computes.  A ragged batch (full, short, tile-boundary and nearly empty

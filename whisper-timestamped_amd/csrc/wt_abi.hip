@@ -91,7 +91,7 @@ int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, 
                   int, int64_t, int64_t, int64_t, hipStream_t);
 int find_start_padding_batch(const float *, int, int, int, int32_t *, hipStream_t);
 int disfluency_batch(const float *, const wt_seg_desc *, int, const int32_t *, int32_t *, double, double, hipStream_t);
-int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, hipStream_t);
+int logmel_batch(const float *, int, int64_t, const int32_t *, const float *, int, int, float *, float *, int32_t *, hipStream_t);
 int capture_rows(const void *, int, int, int, int, const int32_t *, const int32_t *, int, void *, int, int64_t, int64_t,
                  hipStream_t);
 int qk_rows(const void *, const void *, int, int, int, int, int, float, const int32_t *, const int32_t *, int, void *, int,
@@ -257,7 +257,17 @@ int wt_qk_rows_streams(const void *const *q_layers_host, const void *const *k_la
 
 int wt_logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
                     int n_mels, int n_frames, float *mel_out, float *gmax, void *stream) {
-    return wt::logmel_batch(pcm, n_chunks, n_samples, n_valid_samples, mel_fb, n_mels, n_frames, mel_out, gmax,
+    return wt::logmel_batch(pcm, n_chunks, n_samples, n_valid_samples, mel_fb, n_mels, n_frames, mel_out, gmax, nullptr,
+                            (hipStream_t)stream);
+}
+
+int wt_logmel_pad_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
+                        int n_mels, int n_frames, float *mel_out, float *gmax, int32_t *start_of_padding, void *stream) {
+    if (!start_of_padding) {
+        wt::set_error("wt_logmel_pad_batch: start_of_padding is null");
+        return WT_E_BADARG;
+    }
+    return wt::logmel_batch(pcm, n_chunks, n_samples, n_valid_samples, mel_fb, n_mels, n_frames, mel_out, gmax, start_of_padding,
                             (hipStream_t)stream);
 }
 

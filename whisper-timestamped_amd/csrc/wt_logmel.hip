@@ -168,7 +168,12 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ n_valid_samples,
                                                        const float *__restrict__ fb, const int *__restrict__ ws,
                                                        float *__restrict__ wgmax, int n_mels, int n_frames,
-                                                       float *__restrict__ mel_out, int n_wg, int n_tiles) {
+                                                       float *__restrict__ mel_out, int n_wg, int n_tiles,
+                                                       unsigned *__restrict__ pad_code) {
+    // (the padding detector folded into logmel_finalize merges into this word per chunk with atomicMax: zeroed here, a
+    //  whole kernel boundary ahead of its first use)
+    if (pad_code && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < n_tiles / n_wg; c += 256) pad_code[c] = 0u;
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
     static_assert(FPB * 204 >= SPAN_LDS && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
@@ -457,8 +462,16 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
 
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const float *__restrict__ wgmax, int n_wg,
                                                               const int32_t *__restrict__ n_valid_samples, int64_t n_samples,
-                                                              int n_mels, int n_frames, float *__restrict__ gmax) {
+                                                              int n_mels, int n_frames, float *__restrict__ gmax,
+                                                              unsigned *__restrict__ pad_code) {
+    // pad_code (optional): transcribe.py:1795-1805 find_start_padding of the finished window, decided on the VALUES this
+    // pass writes (not on n_valid_samples: a valid column may be exactly zero, a window may have no padding at all).
+    // Every element that is not exactly 0 votes with its column c: code(c) = 0xFFFFFFFF for the last column (-> the
+    // reference's None, read back as int32 -1), c + 1 for 1 <= c <= n_frames - 2 (the index after the last column
+    // that differs from the all-zero last one), 0 for column 0 (the reference's walk stops above it); the unsigned
+    // maximum over the chunk is the answer -- 0 when nothing voted.
     const int chunk = blockIdx.y;
+    int last_nz = -1;
     const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
     const int nvf = min(nvs / 160, n_frames);
     __shared__ float s_mx[4];
@@ -482,6 +495,8 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
                 if (fr + 1 < nvf) v.y = (fmaxf(x.y, floor_v) + 4.0f) / 4.0f;
                 if (fr + 2 < nvf) v.z = (fmaxf(x.z, floor_v) + 4.0f) / 4.0f;
                 if (fr + 3 < nvf) v.w = (fmaxf(x.w, floor_v) + 4.0f) / 4.0f;
+                const int nz = v.w != 0.f ? 3 : v.z != 0.f ? 2 : v.y != 0.f ? 1 : v.x != 0.f ? 0 : -1;
+                if (nz >= 0) last_nz = max(last_nz, fr + nz);
             }
             base4[e4] = v;
         }
@@ -490,10 +505,22 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
             const int fr = e % n_frames;
             float v = 0.f;  // pad_or_trim: exact zeros
             if (fr < nvf) v = (fmaxf(base[e], floor_v) + 4.0f) / 4.0f;
+            if (v != 0.f) last_nz = max(last_nz, fr);
             base[e] = v;
         }
     }
     if (gmax && blockIdx.x == 0 && threadIdx.x == 0) gmax[chunk] = mx;
+    if (pad_code) {                                   // one merge per workgroup (block-uniform condition)
+        __shared__ int s_nz[4];
+        last_nz = wave_max_i(last_nz);
+        if ((threadIdx.x & 63) == 0) s_nz[threadIdx.x >> 6] = last_nz;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int c = max(max(s_nz[0], s_nz[1]), max(s_nz[2], s_nz[3]));
+            const unsigned code = c >= n_frames - 1 ? 0xFFFFFFFFu : (c >= 1 ? (unsigned)(c + 1) : 0u);
+            if (code) atomicMax(pad_code + chunk, code);
+        }
+    }
 }
 
 int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared);
@@ -540,7 +567,7 @@ static int upload_tables(hipStream_t st) {
 }
 
 int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_t *n_valid_samples, const float *mel_fb,
-                 int n_mels, int n_frames, float *mel_out, float *gmax, hipStream_t st) {
+                 int n_mels, int n_frames, float *mel_out, float *gmax, int32_t *start_of_padding, hipStream_t st) {
     if (!pcm || !mel_fb || !mel_out || n_chunks < 0 || n_samples < 201 || n_mels <= 0 || n_mels > MAX_MELS || n_frames <= 0) {
         set_error("wt_logmel_batch: bad argument");
         return WT_E_BADARG;
@@ -565,11 +592,12 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     }
     const int resident = 4 * device_cu_count();   // 39.3 KB of LDS: four workgroups per CU
     hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)std::min<long long>(n_tiles, resident)), dim3(256), 0, st, pcm, n_samples,
-                       n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_wg, (int)n_tiles);
+                       n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_wg, (int)n_tiles,
+                       reinterpret_cast<unsigned *>(start_of_padding));
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, wgmax, n_wg, n_valid_samples,
-                       n_samples, n_mels, n_frames, gmax);
+                       n_samples, n_mels, n_frames, gmax, reinterpret_cast<unsigned *>(start_of_padding));
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -31,7 +31,7 @@ assert SEG_DTYPE.itemsize == 64
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
            "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3",
-           "wt_release_stream", "wt_qk_rows_streams"]
+           "wt_release_stream", "wt_qk_rows_streams", "wt_logmel_pad_batch"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
 ABI_VERSION = 4
 WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS, WT_ALIGN_ROWS_PER_CLASS = 1, 2, 4
@@ -72,6 +72,7 @@ def load():
     L.wt_logprob_gather_rows.argtypes = [vp, i32, i64, vp, i32, i32, vp, vp, vp]
     L.wt_dtw_batch_pattern.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.wt_release_stream.argtypes = [vp]
+    L.wt_logmel_pad_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp]
     L.wt_qk_rows_streams.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, f32, vp, vp, vp, i32, vp, vp, i32, i64,
                                      i64, i64, vp]
     if L.wt_version() != ABI_VERSION:
@@ -375,8 +376,10 @@ def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring: torch
     _check(rc, "wt_qk_rows_batch")
 
 
-def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000):
-    """pcm: (B, n_samples) fp32; mel_fb: (n_mels, 201) fp32.  Returns (mel (B,n_mels,n_frames), gmax (B,))."""
+def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000,
+           with_padding: bool = False):
+    """pcm: (B, n_samples) fp32; mel_fb: (n_mels, 201) fp32.  Returns (mel (B,n_mels,n_frames), gmax (B,)) -- and, with
+    ``with_padding``, find_start_padding of every window (int32[B], -1 = None) from the same two launches."""
     _need_cuda(pcm, "pcm")
     pcm = pcm.contiguous().float()
     mel_fb = mel_fb.to(pcm.device).contiguous().float()
@@ -386,6 +389,13 @@ def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tenso
     mel = torch.empty((B, M, n_frames), dtype=torch.float32, device=pcm.device)
     gmax = torch.empty(B, dtype=torch.float32, device=pcm.device)
     nv = None if n_valid_samples is None else n_valid_samples.to(device=pcm.device, dtype=torch.int32).contiguous()
+    if with_padding:
+        pad = torch.empty(B, dtype=torch.int32, device=pcm.device)
+        with on_device(pcm) as st:
+            rc = load().wt_logmel_pad_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
+                                            gmax.data_ptr(), pad.data_ptr(), st)
+        _check(rc, "wt_logmel_pad_batch")
+        return mel, gmax, pad
     with on_device(pcm) as st:
         rc = load().wt_logmel_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
                                     gmax.data_ptr(), st)

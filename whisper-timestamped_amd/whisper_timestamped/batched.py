@@ -11,7 +11,7 @@ Python loop of ``logprobs[:, step, tok]`` reads (:1285-1300).  With
 do not depend on each other (:1197-1202) -- the ``previous_end`` chain only
 exists in the other branch (:1147-1152) -- so B of them can share every launch:
 
-    PCM (B, 480000) --wt_logmel_batch--> mel (B, n_mels, 3000) --wt_find_start_padding_batch--> pad[B]
+    PCM (B, 480000) --wt_logmel_pad_batch--> mel (B, n_mels, 3000), pad[B] (find_start_padding, same two launches)
     model.encoder / model.decoder on the whole batch (torch: hipBLASLt GEMMs, fused attention)
     cross_attn.query / cross_attn.key outputs of every hooked layer --wt_qk_rows_batch--> rows (B, A, T_max, 1500)
     ONE wt_align_batch over all windows' units --> jumps
@@ -195,8 +195,8 @@ class BatchedAligner:
             tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
             self._mark(st, "logmel<")
             # log-mel of every crop, zero padded to 3000 frames (:1211-1215), and where the padding starts (:1795-1805)
-            mel = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES)
-            pad_copy = _lib.HostCopy(_lib.find_start_padding(mel))
+            mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True)
+            pad_copy = _lib.HostCopy(pad)
             self._mark(st, "logmel>")
             del pcm
             self._mark(st, "model<")
