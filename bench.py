@@ -269,11 +269,11 @@ def make_workload_kreal(dev, cfg, seed):
                 stairs=stairs)
 
 
-# (round 4: the padding detector is part of the log-mel stage -- wt_logmel_pad_batch decides find_start_padding in the
-#  pass that finalises the windows; rounds 1-3 timed a separate "padding" stage of one launch)
+# (round 4: the padding detector is part of the log-mel stage -- wt_logmel_pad_batch: a one-wave-per-window pass behind
+#  the finalising one, which starts its walk at the last valid column; rounds 1-3 timed a separate "padding" stage)
 STAGES = ["logmel", "cost", "dtw", "logprob"]
 # kernels of each stage as rocprofv3 names them (profiles/*traffic.json keys)
-STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel"], "cost": ["rowmean_kernel", "colnorm_kernel", "fix00_kernel"],
+STAGE_KERNELS = {"logmel": ["stft_mel_kernel", "logmel_finalize_kernel", "logmel_init_kernel", "padding_after_finalize_kernel"], "cost": ["rowmean_kernel", "colnorm_kernel", "fix00_kernel"],
                  "dtw": ["dtw_kernel"], "logprob": ["logprob_gather_kernel"]}
 
 

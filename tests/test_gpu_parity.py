@@ -646,8 +646,8 @@ def test_logmel_vs_oracle():
 
 
 def test_logmel_pad_batch_equals_the_detector_run_afterwards():
-    """wt_logmel_pad_batch: find_start_padding decided by the pass that finalises the windows (transcribe.py:1795-1805 on
-    the VALUES it writes) == wt_find_start_padding_batch on the finished windows == the oracle's walk, for full windows
+    """wt_logmel_pad_batch: find_start_padding of the windows it has just written (transcribe.py:1795-1805: the walk starts
+    at the last valid column, the columns behind it being zeros by construction) == wt_find_start_padding_batch on the finished windows == the oracle's walk, for full windows
     (None), ragged ones, tile-boundary and nearly empty ones, a silent one, 80 and 128 mel bins, window sizes that take
     the 16-byte and the scalar path of the pass -- and the mel / max it returns are those of wt_logmel_batch."""
     L = _lib()

@@ -128,3 +128,42 @@ def test_calls_the_batched_path_cannot_take_run_one_by_one(monkeypatch):
     with pytest.raises(AssertionError, match="unknown options"):
         wt.transcribe_batch(None, [torch.zeros(16000)], not_an_option=1)
     assert wt.transcribe_batch(None, []) == []
+
+
+def test_batched_timestamp_rules_equal_the_backends_row_by_row(monkeypatch):
+    """streams.BatchedTimestampRules against the backend's ApplyTimestampRules on random token histories -- no
+    timestamps yet, open pairs, closed pairs, text after a pair, the first sampled position, rows of one batch in
+    different states: identical logits (values and -inf pattern)."""
+    import numpy as np
+    import whisper_double as W
+    from whisper_timestamped import streams
+    W.install()
+    tk = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    ts0, V = tk.timestamp_begin, 51865
+    rng = np.random.RandomState(5)
+    g = torch.Generator().manual_seed(5)
+    for sample_begin, max_initial in ((4, 50), (4, None), (9, 50)):
+        theirs = W.decoding.ApplyTimestampRules(tk, sample_begin, max_initial)
+        mine = streams.BatchedTimestampRules.like(theirs)
+        for n in (0, 1, 2, 3, 7, 30):
+            rows = []
+            for b in range(9):
+                seq, t = [], int(rng.randint(0, 100))
+                while len(seq) < n:
+                    kind = rng.randint(4) if seq else 0
+                    if kind == 0:                       # an opening timestamp
+                        t += int(rng.randint(0, 40))
+                        seq.append(ts0 + t)
+                    elif kind == 1 and seq[-1] >= ts0:  # its twin
+                        seq.append(seq[-1] if rng.rand() < 0.5 else ts0 + t + int(rng.randint(0, 9)))
+                    else:
+                        seq.append(int(rng.randint(300, 40000)))
+                rows.append([50258, 50259, 50359, ts0 - 1][:min(4, sample_begin)] + [11] * (sample_begin - 4) + seq[:n])
+            tokens = torch.tensor(rows)
+            logits = torch.randn((len(rows), V), generator=g) * 3
+            logits[:, ts0:] += float(rng.choice([-4.0, 0.0, 4.0]))        # both outcomes of the timestamp-mass rule
+            a, b = logits.clone(), logits.clone()
+            theirs.apply(a, tokens)
+            mine.apply(b, tokens)
+            assert torch.equal(torch.isinf(a), torch.isinf(b)), (sample_begin, n)
+            assert torch.equal(a, b), (sample_begin, n)

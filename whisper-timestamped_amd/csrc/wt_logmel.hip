@@ -168,12 +168,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ n_valid_samples,
                                                        const float *__restrict__ fb, const int *__restrict__ ws,
                                                        float *__restrict__ wgmax, int n_mels, int n_frames,
-                                                       float *__restrict__ mel_out, int n_wg, int n_tiles,
-                                                       unsigned *__restrict__ pad_code) {
-    // (the padding detector folded into logmel_finalize merges into this word per chunk with atomicMax: zeroed here, a
-    //  whole kernel boundary ahead of its first use)
-    if (pad_code && blockIdx.x == 0)
-        for (int c = threadIdx.x; c < n_tiles / n_wg; c += 256) pad_code[c] = 0u;
+                                                       float *__restrict__ mel_out, int n_wg, int n_tiles) {
     // 39.3 KB of LDS -> 4 workgroups (16 waves) per CU.  `pw` (stage-2 output) reuses the PCM span, which is dead
     // after stage 1 (a barrier separates them).
     static_assert(FPB * 204 >= SPAN_LDS && FPB * 204 >= 201 * FPB, "the span and the power spectrum share a buffer");
@@ -462,16 +457,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float *__restrict__
 
 __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict__ mel_out, const float *__restrict__ wgmax, int n_wg,
                                                               const int32_t *__restrict__ n_valid_samples, int64_t n_samples,
-                                                              int n_mels, int n_frames, float *__restrict__ gmax,
-                                                              unsigned *__restrict__ pad_code) {
-    // pad_code (optional): transcribe.py:1795-1805 find_start_padding of the finished window, decided on the VALUES this
-    // pass writes (not on n_valid_samples: a valid column may be exactly zero, a window may have no padding at all).
-    // Every element that is not exactly 0 votes with its column c: code(c) = 0xFFFFFFFF for the last column (-> the
-    // reference's None, read back as int32 -1), c + 1 for 1 <= c <= n_frames - 2 (the index after the last column
-    // that differs from the all-zero last one), 0 for column 0 (the reference's walk stops above it); the unsigned
-    // maximum over the chunk is the answer -- 0 when nothing voted.
+                                                              int n_mels, int n_frames, float *__restrict__ gmax) {
     const int chunk = blockIdx.y;
-    int last_nz = -1;
+
     const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
     const int nvf = min(nvs / 160, n_frames);
     __shared__ float s_mx[4];
@@ -495,8 +483,6 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
                 if (fr + 1 < nvf) v.y = (fmaxf(x.y, floor_v) + 4.0f) / 4.0f;
                 if (fr + 2 < nvf) v.z = (fmaxf(x.z, floor_v) + 4.0f) / 4.0f;
                 if (fr + 3 < nvf) v.w = (fmaxf(x.w, floor_v) + 4.0f) / 4.0f;
-                const int nz = v.w != 0.f ? 3 : v.z != 0.f ? 2 : v.y != 0.f ? 1 : v.x != 0.f ? 0 : -1;
-                if (nz >= 0) last_nz = max(last_nz, fr + nz);
             }
             base4[e4] = v;
         }
@@ -505,22 +491,39 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(float *__restrict_
             const int fr = e % n_frames;
             float v = 0.f;  // pad_or_trim: exact zeros
             if (fr < nvf) v = (fmaxf(base[e], floor_v) + 4.0f) / 4.0f;
-            if (v != 0.f) last_nz = max(last_nz, fr);
             base[e] = v;
         }
     }
     if (gmax && blockIdx.x == 0 && threadIdx.x == 0) gmax[chunk] = mx;
-    if (pad_code) {                                   // one merge per workgroup (block-uniform condition)
-        __shared__ int s_nz[4];
-        last_nz = wave_max_i(last_nz);
-        if ((threadIdx.x & 63) == 0) s_nz[threadIdx.x >> 6] = last_nz;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int c = max(max(s_nz[0], s_nz[1]), max(s_nz[2], s_nz[3]));
-            const unsigned code = c >= n_frames - 1 ? 0xFFFFFFFFu : (c >= 1 ? (unsigned)(c + 1) : 0u);
-            if (code) atomicMax(pad_code + chunk, code);
-        }
+}
+
+// transcribe.py:1795-1805 find_start_padding of the windows logmel_finalize has just written, ONE WAVE per window.
+// The reference walks back from column n_frames - 2 until a column differs from the (all-zero) last one.  Here the
+// columns behind the valid frames are exact zeros BY CONSTRUCTION of the pass above, so the walk starts at the last
+// valid column instead of re-reading up to 1500 columns of zeros (what wt_find_start_padding_batch has to do for a
+// mel it knows nothing about: 18-65 us per batch); everything it decides, it decides on VALUES: the last column, and
+// every column from the last valid one downwards until one is not all-zero (normally the first one it looks at).
+// (Folding the decision into logmel_finalize itself was built first: one atomicMax per workgroup and window -- ~118
+// device-scope atomics per address -- cost +35 us on the 11 us pass: profiles/r4d_bench.json, logmel stage 0.104 ms.)
+__global__ __launch_bounds__(64) void padding_after_finalize_kernel(const float *__restrict__ mel, const int32_t *__restrict__ n_valid_samples,
+                                                                    int64_t n_samples, int n_mels, int n_frames,
+                                                                    int32_t *__restrict__ out) {
+    const int chunk = blockIdx.x, lane = threadIdx.x;
+    const float *base = mel + (int64_t)chunk * n_mels * n_frames;
+    auto column_all_zero = [&](int c) {
+        bool nz = false;
+        for (int m = lane; m < n_mels; m += 64) nz |= base[(int64_t)m * n_frames + c] != 0.f;
+        return __ballot(nz) == 0ull;                       // wave-uniform
+    };
+    if (!column_all_zero(n_frames - 1)) {                  // min == max == 0 fails -> None
+        if (lane == 0) out[chunk] = -1;
+        return;
     }
+    const int nvs = n_valid_samples ? n_valid_samples[chunk] : (int)n_samples;
+    const int nvf = min(nvs / 160, n_frames);
+    int c = min(nvf, n_frames - 1) - 1;                    // columns nvf .. n_frames - 1 are zeros (written so above)
+    while (c > 0 && column_all_zero(c)) --c;
+    if (lane == 0) out[chunk] = c > 0 ? c + 1 : 0;
 }
 
 int scratch_tagged(hipStream_t st, size_t bytes, void **out, const void *tag_ptr, long long tag_val, bool *prepared);
@@ -592,12 +595,14 @@ int logmel_batch(const float *pcm, int n_chunks, int64_t n_samples, const int32_
     }
     const int resident = 4 * device_cu_count();   // 39.3 KB of LDS: four workgroups per CU
     hipLaunchKernelGGL(stft_mel_kernel, dim3((unsigned)std::min<long long>(n_tiles, resident)), dim3(256), 0, st, pcm, n_samples,
-                       n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_wg, (int)n_tiles,
-                       reinterpret_cast<unsigned *>(start_of_padding));
+                       n_valid_samples, mel_fb, ws, wgmax, n_mels, n_frames, mel_out, n_wg, (int)n_tiles);
     const int total = n_mels * n_frames;
     int gx = (total + 256 * 8 - 1) / (256 * 8);
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(gx, n_chunks), dim3(256), 0, st, mel_out, wgmax, n_wg, n_valid_samples,
-                       n_samples, n_mels, n_frames, gmax, reinterpret_cast<unsigned *>(start_of_padding));
+                       n_samples, n_mels, n_frames, gmax);
+    if (start_of_padding)
+        hipLaunchKernelGGL(padding_after_finalize_kernel, dim3(n_chunks), dim3(64), 0, st, mel_out, n_valid_samples, n_samples,
+                           n_mels, n_frames, start_of_padding);
     WT_HIP(hipGetLastError());
     return WT_OK;
 }

@@ -379,7 +379,7 @@ def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring: torch
 def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000,
            with_padding: bool = False):
     """pcm: (B, n_samples) fp32; mel_fb: (n_mels, 201) fp32.  Returns (mel (B,n_mels,n_frames), gmax (B,)) -- and, with
-    ``with_padding``, find_start_padding of every window (int32[B], -1 = None) from the same two launches."""
+    ``with_padding``, find_start_padding of every window (int32[B], -1 = None) by a one-wave-per-window pass that starts at the last valid column."""
     _need_cuda(pcm, "pcm")
     pcm = pcm.contiguous().float()
     mel_fb = mel_fb.to(pcm.device).contiguous().float()

@@ -11,7 +11,7 @@ Python loop of ``logprobs[:, step, tok]`` reads (:1285-1300).  With
 do not depend on each other (:1197-1202) -- the ``previous_end`` chain only
 exists in the other branch (:1147-1152) -- so B of them can share every launch:
 
-    PCM (B, 480000) --wt_logmel_pad_batch--> mel (B, n_mels, 3000), pad[B] (find_start_padding, same two launches)
+    PCM (B, 480000) --wt_logmel_pad_batch--> mel (B, n_mels, 3000), pad[B] (find_start_padding, a 3 us pass behind it)
     model.encoder / model.decoder on the whole batch (torch: hipBLASLt GEMMs, fused attention)
     cross_attn.query / cross_attn.key outputs of every hooked layer --wt_qk_rows_batch--> rows (B, A, T_max, 1500)
     ONE wt_align_batch over all windows' units --> jumps

@@ -193,6 +193,70 @@ class _SliceOfCopy:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the backend's timestamp rules, all rows at once
+# ----------------------------------------------------------------------------------------------------------------------
+# openai-whisper's ApplyTimestampRules.apply (whisper/decoding.py) walks the batch ROW BY ROW on the host: a .tolist()
+# of the row's sampled tokens, up to three slice assignments, a logsumexp / max / comparison -- the comparison being a
+# device -> host synchronisation per row.  With one stream that is noise; with 32 streams it was HALF of the wall time
+# of a decoder loop (profiles/r4d_profile_streams.txt: 0.52 of 1.06 s).  Same rules, same masks, computed for all rows
+# on the device with no host read: the driver swaps this object for the backend's inside the task it drives
+# (VECTORIZED_TIMESTAMP_RULES = False keeps the backend's own).  Held against the backend's class on random token
+# histories (tests/test_streams_host.py): identical logits.
+VECTORIZED_TIMESTAMP_RULES = True
+
+
+class BatchedTimestampRules:
+    def __init__(self, tokenizer, sample_begin, max_initial_timestamp_index):
+        self.tokenizer, self.sample_begin = tokenizer, sample_begin
+        self.max_initial_timestamp_index = max_initial_timestamp_index
+        self._col = None
+
+    @classmethod
+    def like(cls, rule):
+        return cls(rule.tokenizer, rule.sample_begin, rule.max_initial_timestamp_index)
+
+    def apply(self, logits, tokens):
+        tk = self.tokenizer
+        ts0, eot, V = tk.timestamp_begin, tk.eot, logits.shape[-1]
+        if tk.no_timestamps is not None:
+            logits[:, tk.no_timestamps] = -np.inf
+        if self._col is None or self._col.device != logits.device or self._col.numel() != V:
+            self._col = torch.arange(V, device=logits.device)
+        col = self._col[None]
+        sampled = tokens[:, self.sample_begin:].to(logits.device)
+        B, n = sampled.shape
+        if n >= 1:
+            is_ts = sampled >= ts0
+            last = is_ts[:, -1]
+            penult = is_ts[:, -2] if n >= 2 else torch.ones(B, dtype=torch.bool, device=logits.device)
+            # timestamps come in pairs, except right before eot
+            mask = ((last & penult)[:, None] & (col >= ts0)) | ((last & ~penult)[:, None] & (col < eot))
+            # timestamps never decrease: below the LAST timestamp of the row (+ 1 unless it opens a pair)
+            pos = torch.arange(n, device=logits.device)[None]
+            where_last = torch.where(is_ts, pos, torch.full_like(pos, -1)).max(dim=1).values      # -1: no timestamp yet
+            any_ts = where_last >= 0
+            last_ts = sampled.gather(1, where_last.clamp(min=0)[:, None])[:, 0]
+            bound = last_ts + torch.where(last & ~penult, 0, 1)
+            mask |= any_ts[:, None] & (col >= ts0) & (col < bound[:, None])
+            logits.masked_fill_(mask, -np.inf)
+        if tokens.shape[1] == self.sample_begin:
+            logits[:, :ts0] = -np.inf                  # the first sampled token is a timestamp
+            if self.max_initial_timestamp_index is not None:
+                logits[:, ts0 + self.max_initial_timestamp_index + 1:] = -np.inf
+        # the total timestamp mass above any text token -> a timestamp it is
+        logprobs = torch.nn.functional.log_softmax(logits.float(), dim=-1)
+        take_ts = logprobs[:, ts0:].logsumexp(dim=-1) > logprobs[:, :ts0].max(dim=-1).values
+        logits[:, :ts0].masked_fill_(take_ts[:, None], -np.inf)
+
+
+def vectorize_filters(task):
+    if VECTORIZED_TIMESTAMP_RULES:
+        task.logit_filters = [BatchedTimestampRules.like(f) if type(f).__name__ == "ApplyTimestampRules" else f
+                              for f in task.logit_filters]
+    return task
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # recorder: the hooks of ONE batched decoder loop
 # ----------------------------------------------------------------------------------------------------------------------
 class _Recorder:
@@ -547,7 +611,7 @@ def _run_streams(model, audios, opts, **session_kwargs):
                 grp = [act[j] for j in members]
                 if ON_GROUP_DECODE is not None:
                     ON_GROUP_DECODE([s.index for s in grp])
-                task = grp[0].task
+                task = vectorize_filters(grp[0].task)
                 ring_index = torch.tensor([s.index for s in grp], dtype=torch.int32, device=dev)
                 rec = _Recorder(model, rings, hooked_blocks, ring_index, verify=verify)
                 rec.fused_checked = fused_checked or not efficient.FUSED_ATTENTION
