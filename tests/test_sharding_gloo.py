@@ -128,14 +128,18 @@ def _islands_job():
     return json.load(open(os.path.join(ROOT, "tests", "golden", "islands_job.json"), encoding="utf-8"))
 
 
-def _run_islands_job(dist, job, patch, device="cpu"):
+def _run_islands_job(dist, job, patch, device="cpu", streams=0):
     import cpu_kernel_standin
     import whisper_double as W
     from golden import make_golden_transcribe as G
-    from whisper_double.decoding import Script, set_script
+    from whisper_double.decoding import Script, set_row_scripts, set_script
     if patch is not None:
         cpu_kernel_standin.install(patch)
+        if streams:
+            from test_streams_host import install_streams_standin
+            install_streams_standin(patch)
     W.install()
+    from whisper_timestamped import streams as streams_mod
     from whisper_timestamped.sharding import transcribe_islands
     model, audio, _ = G.build_case(dict(job, script=None), device=device)
     rank = 0 if dist is None else dist.get_rank()
@@ -149,11 +153,24 @@ def _run_islands_job(dist, job, patch, device="cpu"):
     def on_island(i):
         seen.append(i)
         set_script(Script(job["recorded"][i]))       # replay what the reference's decoder sampled on this island
+
+    def on_batch(indices):                           # streams: one script per island, routed to its row of every decoder loop
+        seen.extend(indices)
+        scripts = [Script(job["recorded"][i]) for i in indices]
+        base = [0]
+
+        def on_group(rows):
+            for r in rows:
+                scripts[base[0] + r].begin_window()
+            set_row_scripts([scripts[base[0] + r] for r in rows])     # (streams >= islands per rank here: one chunk)
+        streams_mod.ON_GROUP_DECODE = on_group
     try:
         result = transcribe_islands(model, audio, job["islands"], dist=dist, broadcast_weights=True, on_island=on_island,
-                                    fp16=False, **job["opts"])
+                                    streams=streams, on_batch=on_batch, fp16=False, **job["opts"])
     finally:
         set_script(None)
+        set_row_scripts(None)
+        streams_mod.ON_GROUP_DECODE = None
     return result, seen
 
 
@@ -187,7 +204,16 @@ def test_islands_job_single_rank(monkeypatch):
     _check_islands_result(result, job)
 
 
-def _islands_worker(rank, world, port, out_path):
+def test_islands_job_single_rank_islands_as_decoder_streams(monkeypatch):
+    """The same job with the rank's islands stepping through the decoder together (streams = 4): per island the
+    reference's output, as one after the other."""
+    job = _islands_job()
+    result, seen = _run_islands_job(None, job, monkeypatch, streams=4)
+    assert sorted(seen) == [0, 1, 2, 3]
+    _check_islands_result(result, job)
+
+
+def _islands_worker(rank, world, port, out_path, streams=0):
     for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -197,7 +223,7 @@ def _islands_worker(rank, world, port, out_path):
     patch = pytest.MonkeyPatch()
     try:
         job = _islands_job()
-        result, seen = _run_islands_job(dist, job, patch)
+        result, seen = _run_islands_job(dist, job, patch, streams=streams)
         owned = [None] * world
         dist.all_gather_object(owned, seen)
         assert sorted(i for part in owned for i in part) == [0, 1, 2, 3] and all(len(part) > 0 for part in owned)
@@ -216,6 +242,15 @@ def _islands_worker(rank, world, port, out_path):
 def test_islands_job_two_ranks(tmp_path):
     out = tmp_path / "islands.txt"
     mp.spawn(_islands_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text().startswith("ok ")
+
+
+@pytest.mark.timeout(600)
+def test_islands_job_two_ranks_islands_as_decoder_streams(tmp_path):
+    """BASELINE configs[3] in its MI355X shape: islands dealt to the ranks (no data-path collective), and each rank's
+    islands decoded together, several streams per decoder op."""
+    out = tmp_path / "islands_streams.txt"
+    mp.spawn(_islands_worker, args=(2, _free_port(), str(out), 4), nprocs=2, join=True)
     assert out.read_text().startswith("ok ")
 
 

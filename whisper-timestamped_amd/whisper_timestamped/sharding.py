@@ -161,7 +161,7 @@ def share_audio(dist, audio, device, src: int = 0):
 
 
 def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool = False, on_island=None,
-                       sample_rate: int = 16000, **options):
+                       sample_rate: int = 16000, streams: int = 0, on_batch=None, **options):
     """One long recording, many ranks.  `islands` = [(start_s, end_s)] speech islands (an explicit VAD list: the
     reference's `vad=[...]` form, transcribe.py:1944-1947); every island is an independent unit -- exactly the
     reference's transcribe() on that island's crop -- so they are dealt to the ranks largest-first by duration with
@@ -171,7 +171,10 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
     Not the reference's `vad=` mode (that one glues the islands and decodes them as ONE stream, which cannot be split
     without changing what the decoder is conditioned on); per island the results are the reference's.
     `audio`: what transcribe() accepts (path, ndarray, 1-D tensor), on rank 0 (None elsewhere -> broadcast) or on every rank.  `on_island(i)` is called
-    before island i is transcribed (progress / test scripting).  `options` go to transcribe_timestamped()."""
+    before island i is transcribed (progress / test scripting).  `options` go to transcribe_timestamped().
+    `streams` > 1: a rank's islands are independent recordings, so they step through the decoder TOGETHER, up to
+    `streams` of them per decoder op (transcribe_batch -> streams.py) instead of one after the other; `on_batch(indices)`
+    is then called once per rank with its island indices in stream order.  Same per-island results."""
     from .naive import get_audio_tensor
     from .transcribe import transcribe_timestamped
     if audio is not None:
@@ -186,12 +189,20 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
         audio = share_audio(dist, audio, model.device)
     parts = partition_units([e - s for s, e in islands], world)
     mine = []
-    for i in parts[rank]:
-        s, e = islands[i]
-        crop = audio[int(round(s * sample_rate)):int(round(e * sample_rate))]
-        if on_island is not None:
-            on_island(i)
-        mine.append((i, transcribe_timestamped(model, crop, **options)))
+    if streams and streams > 1:
+        from .transcribe import transcribe_batch
+        idx = list(parts[rank])
+        crops = [audio[int(round(islands[i][0] * sample_rate)):int(round(islands[i][1] * sample_rate))] for i in idx]
+        if on_batch is not None:
+            on_batch(idx)
+        mine = list(zip(idx, transcribe_batch(model, crops, max_streams=streams, **options)))
+    else:
+        for i in parts[rank]:
+            s, e = islands[i]
+            crop = audio[int(round(s * sample_rate)):int(round(e * sample_rate))]
+            if on_island is not None:
+                on_island(i)
+            mine.append((i, transcribe_timestamped(model, crop, **options)))
     if world > 1:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(mine, gathered, dst=0)
