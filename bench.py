@@ -1049,7 +1049,7 @@ def run_efficient_leg(args, emit):
       1_stream        what a caller of the reference's API gets per process: transcribe(model, clip), one decoder stream,
                       one token at a time through the backend's own Python loop;
       B_streams       transcribe_batch(model, clips): B independent recordings stepping through the decoder together
-                      (whisper_timestamped/streams.py), B = --e2e-streams (32 = BASELINE configs[1]'s batch);
+                      (whisper_timestamped/streams.py), B = --e2e-streams (32 = BASELINE configs[1]'s batch), and 4 B;
       cpu_baseline    the reference-shaped CPU path for the same clips: the same model on the host cores, unfused
                       attention with per-token QK capture, a second projection + logit filters per token, one
                       synchronous alignment per segment through oracle/ (the reference's shape, T.py:783-793,849-881,
@@ -1109,27 +1109,29 @@ def run_efficient_leg(args, emit):
         finally:
             streams.ON_GROUP_DECODE = None
             set_row_scripts(None)
-    many(B)                                                 # warm-up at the timed shape
-    torch.cuda.synchronize()
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        batch = many(B)
-    torch.cuda.synchronize()
-    elB = (time.perf_counter() - t0) / reps
-    worst_t = worst_c = 0.0
-    for k, r in enumerate(batch):
-        a, b = words_of(r), words_of(singles[k % len(clips)])
-        assert [x[0] for x in a] == [x[0] for x in b], "B-stream and one-stream words differ"
-        worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
-        worst_c = max([worst_c] + [abs(x[3] - y[3]) for x, y in zip(a, b)])
-    out[f"{B}_streams"] = {"audio_s_per_s": round(30.0 * B / elB, 1), "clips": B, "seconds": round(elB, 3),
-                           "ms_per_clip": round(1e3 * elB / B, 2), "words": sum(len(words_of(r)) for r in batch),
-                           "speedup_vs_1_stream": round((30.0 * B / elB) / (30.0 * len(clips) / el1), 2),
-                           "driver": dict(streams.LAST_RUN),
-                           "parity_vs_1_stream": {"max_abs_dt_word_s": round(worst_t, 4), "max_abs_dconfidence": round(worst_c, 6)}}
-    assert worst_t <= 0.02 + 1e-9 and worst_c <= 1e-3 + 1e-9, out[f"{B}_streams"]
-    emit(out)
+    for n_streams in (B, 4 * B):
+        many(n_streams)                                     # warm-up at the timed shape
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            batch = many(n_streams)
+        torch.cuda.synchronize()
+        elB = (time.perf_counter() - t0) / reps
+        worst_t = worst_c = 0.0
+        for k, r in enumerate(batch):
+            a, b = words_of(r), words_of(singles[k % len(clips)])
+            assert [x[0] for x in a] == [x[0] for x in b], "B-stream and one-stream words differ"
+            worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
+            worst_c = max([worst_c] + [abs(x[3] - y[3]) for x, y in zip(a, b)])
+        key = f"{n_streams}_streams"
+        out[key] = {"audio_s_per_s": round(30.0 * n_streams / elB, 1), "clips": n_streams, "seconds": round(elB, 3),
+                    "ms_per_clip": round(1e3 * elB / n_streams, 2), "words": sum(len(words_of(r)) for r in batch),
+                    "speedup_vs_1_stream": round((30.0 * n_streams / elB) / (30.0 * len(clips) / el1), 2),
+                    "driver": dict(streams.LAST_RUN),
+                    "parity_vs_1_stream": {"max_abs_dt_word_s": round(worst_t, 4), "max_abs_dconfidence": round(worst_c, 6)}}
+        assert worst_t <= 0.02 + 1e-9 and worst_c <= 1e-3 + 1e-9, out[key]
+        emit(out)
 
     # ---- the reference-shaped CPU path, same clips (bounded sample)
     if not args.no_cpu_baseline:
@@ -1173,8 +1175,8 @@ def run_efficient_leg(args, emit):
                                          f"whisper-base on the CPU, unfused attention with per-token QK capture, second projection "
                                          f"+ logit filters per token, one alignment per segment through oracle/"}
         out["parity_vs_cpu_reference_path"] = {"clips": done, "max_abs_dt_word_s": round(worst_t, 4)}
-        out["speedup_vs_cpu"] = {"1_stream": round(out["1_stream"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1),
-                                 f"{B}_streams": round(out[f"{B}_streams"]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)}
+        out["speedup_vs_cpu"] = {k: round(out[k]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)
+                                 for k in ("1_stream", f"{B}_streams", f"{4 * B}_streams")}
         emit(out)
     return out
 

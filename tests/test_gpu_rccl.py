@@ -106,7 +106,13 @@ def _one_rank_worker(rank, world, port, out_path, gpu_per_rank=False):
         owned = [None] * world
         dist.all_gather_object(owned, seen)
         assert sorted(i for part in owned for i in part) == [0, 1, 2, 3]
+        # 3b. the same job with every rank's islands stepping through the decoder together (streams.py)
+        t0 = time.perf_counter()
+        result_s, _ = _run_islands_job(dist, job, None, device=f"cuda:{gpu}", streams=4)
+        report["islands_job_as_streams_s"] = round(time.perf_counter() - t0, 3)
         if rank == 0:
+            dt, dc = _check_islands_result(result_s, job, time_tol=0.02, conf_tol=1e-3 + 1e-4)
+            report["islands_as_streams_max_abs_dt_s"] = round(dt, 4)
             report["islands_per_rank"] = owned
             with open(out_path, "w") as f:
                 json.dump(report, f)
