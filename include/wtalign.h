@@ -136,7 +136,9 @@ WT_API int wt_qk_rows_streams(const void *const *q_layers_host, const void *cons
                               const int32_t *sel_slot, int n_sel, const int32_t *ring_index, void *ring, int ring_dtype,
                               int64_t ring_batch_stride, int64_t ring_rows, int64_t ring_row0, void *stream);
 
-/* T.py:1540-1568.  For each unit: select heads, median filter (width 9,
+/* T.py:1540-1568.  For each unit: select heads, median filter (medfilt_width: 9 is the reference's default and what
+ * every caller passes -- the tuned path; the other odd widths 1, 3, 5, 7 of the seam's parameter, T.py:1439, are
+ * served by a per-class launch; even widths and widths > 9 are refused with WT_E_UNSUPPORTED;
  * scipy 'reflect' = half-sample symmetric edges) along frames, * qk_scale,
  * softmax over the F-frame window, mean over heads, divide by the per-frame L2
  * norm over tokens, negate, zero rows[:-1] of columns >= pad_from, then

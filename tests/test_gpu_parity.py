@@ -192,7 +192,7 @@ def test_dtw_largest_shape_is_supported():
 
 
 # ---------------------------------------------------------------------------
-def run_cost(qk_list, heads_list, windows, pads, dtype=torch.float32):
+def run_cost(qk_list, heads_list, windows, pads, dtype=torch.float32, medfilt_width=9):
     """qk_list[k]: (L*H, T, 1500) numpy; heads_list: flat head indices (shared); windows[k]=(start,end)."""
     L = _lib()
     n = len(qk_list)
@@ -209,17 +209,17 @@ def run_cost(qk_list, heads_list, windows, pads, dtype=torch.float32):
     hi = torch.tensor(heads_list, dtype=torch.int32, device=DEV)
     cost = torch.full((n_cost,), float("nan"), dtype=torch.float32, device=DEV)
     dd = L.descs_to_device(descs, DEV)
-    L.cost_batch(qk, descs, dd, hi, cost)
+    L.cost_batch(qk, descs, dd, hi, cost, medfilt_width=medfilt_width)
     torch.cuda.synchronize()
     c = cost.cpu().numpy()
     return [c[d["cost_offset"]:d["cost_offset"] + d["T"] * d["F"]].reshape(d["T"], d["F"]) for d in descs]
 
 
-def oracle_cost(q, heads, window, pad):
+def oracle_cost(q, heads, window, pad, medfilt_width=9):
     s, e = window
     sel = torch.from_numpy(q[heads][:, :, s:e])
     md = pad if pad >= 0 else None
-    return O.cost_matrix_ref(sel, 9, 1.0, md, 0 if md else 0)
+    return O.cost_matrix_ref(sel, medfilt_width, 1.0, md, 0 if md else 0)
 
 
 def test_cost_matches_oracle():
@@ -244,6 +244,44 @@ def test_cost_matches_oracle():
             assert (g[:-1, p:] == 0).all() or (p == 0)
         assert g[0, 0] == g.min()
     print(f"max relative cost error vs oracle: {worst:.3e}")
+
+
+@pytest.mark.parametrize("width", [1, 3, 5, 7])
+def test_cost_other_median_widths_match_the_oracle(width):
+    """medfilt_width is a parameter of the seam (transcribe.py:1439; scipy.ndimage.median_filter(w, (1, 1, width)), the
+    reference's default and only caller value being 9): the odd widths below 9 against the oracle's scipy call, every F
+    class, windows shorter than the filter, fp32 and fp16 rows; even widths and widths above 9 are refused."""
+    L = _lib()
+    heads = [1, 3, 4, 7, 9, 10]
+    shapes = [(2, 0, 3), (3, 10, 14), (4, 5, 7), (8, 100, 245), (18, 275, 523), (11, 1, 258), (30, 0, 769), (9, 0, 1025),
+              (20, 0, 1281), (33, 219, 1500), (5, 0, 1)]
+    qs = [synth.synth_qk(500 + k, 12, T, lo=s, hi=e) for k, (T, s, e) in enumerate(shapes)]
+    windows = [(s, e) for _, s, e in shapes]
+    pads = [-1 if k % 2 else max((e - s) // 2, 1) for k, (_, s, e) in enumerate(shapes)]
+    for q, w, p, g in zip(qs, windows, pads, run_cost(qs, heads, windows, pads, medfilt_width=width)):
+        ref = oracle_cost(q, heads, w, p, medfilt_width=width)
+        assert np.abs(g.astype(np.float64) - ref).max() / np.abs(ref).max() < 2e-6, (width, w)
+        assert g[0, 0] == g.min()
+    qh = [q.astype(np.float16).astype(np.float32) for q in qs]
+    for q, w, p, g in zip(qh, windows, pads, run_cost(qh, heads, windows, pads, dtype=torch.float16, medfilt_width=width)):
+        ref = oracle_cost(q, heads, w, p, medfilt_width=width)
+        assert np.abs(g.astype(np.float64) - ref).max() / np.abs(ref).max() < 2e-6, (width, w, "fp16")
+    if width == 1:
+        for bad in (0, 2, 8, 11):
+            with pytest.raises(L.WtError, match="medfilt_width"):
+                run_cost(qs[:1], heads, windows[:1], pads[:1], medfilt_width=bad)
+        # the seam itself: perform_word_alignment(medfilt_width=5) == the oracle's
+        import whisper_timestamped as wt
+        tok = synth.StubTokenizer()
+        tokens = synth.synth_segment_tokens(9, 12, 100, 380, tok)
+        qk = synth.synth_qk(9, 48, len(tokens), lo=75, hi=405).reshape(6, 1, 8, len(tokens), 1500)
+        att = [torch.from_numpy(qk[l]) for l in range(6)]
+        hp = np.array([(3, 1), (4, 2), (5, 4)])
+        got = wt.perform_word_alignment(tokens, [a.to(DEV) for a in att], tok, alignment_heads=hp, medfilt_width=5,
+                                        refine_whisper_precision_nframes=25, detect_disfluencies=False)
+        want = O.perform_word_alignment_ref(tokens, att, tok, alignment_heads=hp, medfilt_width=5,
+                                            refine_whisper_precision_nframes=25, detect_disfluencies=False)
+        assert [(w["text"], w["start"], w["end"]) for w in got] == [(w["text"], w["start"], w["end"]) for w in want]
 
 
 def test_cost_fp16_input_close_to_fp32_oracle():

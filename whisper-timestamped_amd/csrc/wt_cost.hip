@@ -32,7 +32,7 @@ namespace wt {
 
 // One token row of one unit: the head mean of softmax(median9(.)) -> cost[t, :].  ONE WAVE; `lds` = this wave's NB row
 // buffers (wt_cost_core.h).  C = elements per lane; an instantiation can serve any F <= C*64.
-template <int C, typename QT, int NB = 2>
+template <int C, typename QT, int NB = 2, int MW = 9>
 __device__ __forceinline__ void rowmean_row(const QT *__restrict__ qk, const wt_seg_desc &d, int t, const int32_t *__restrict__ head_idx,
                                             int n_heads, float qk_scale, float *__restrict__ cost, float (*lds)[RowBuf<C, QT>::BUF],
                                             int lane) {
@@ -41,7 +41,7 @@ __device__ __forceinline__ void rowmean_row(const QT *__restrict__ qk, const wt_
     const int F = d.F;
     const QT *row0 = qk + d.qk_offset + (int64_t)t * d.row_stride + d.start_token;
     f2 acc[C / 2];
-    head_sum_row<C, QT, NB>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds, lane, acc);
+    head_sum_row<C, QT, NB, MW>(row0, d.head_stride, head_idx, n_heads, F, qk_scale, lds, lane, acc);
 
     // mean over heads (torch CPU: sum then div), back through LDS for a coalesced store
     const float nh = (float)n_heads;
@@ -87,6 +87,31 @@ __global__ __launch_bounds__(256) void rowmean_kernel(const QT *__restrict__ qk,
     if (EXACT) __builtin_assume(F > (C - 4) * 64);
     if (t == 0 && lane == 0) segstate[unit] = 0u;  // per-unit max |cost| bits for colnorm (saves a memset node)
     rowmean_row<C, QT>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane);
+}
+
+// The same launch for the other median widths of the seam (transcribe.py:1439 medfilt_width; odd, < 9): the width is a
+// launch argument, every width its own body.  Not a tuned path (no caller of the reference passes anything but 9): one
+// pipelined launch per F class, whatever the batch size.
+template <int C, typename QT>
+__global__ __launch_bounds__(256) void rowmean_medw_kernel(const QT *__restrict__ qk, const wt_seg_desc *__restrict__ segs,
+                                                           const int32_t *__restrict__ head_idx, int n_heads, float qk_scale,
+                                                           float *__restrict__ cost, unsigned *__restrict__ segstate, int unit0,
+                                                           int f_lo, int f_hi, int medfilt_width) {
+    __shared__ __attribute__((aligned(16))) float lds[4][2][RowBuf<C, QT>::BUF];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int unit = unit0 + blockIdx.y;
+    const wt_seg_desc d = segs[unit];
+    const int F = d.F;
+    const int t = blockIdx.x * 4 + wave;
+    if (F <= f_lo || F > f_hi || t >= d.T) return;
+    if (t == 0 && lane == 0) segstate[unit] = 0u;
+    switch (medfilt_width) {
+        case 1: rowmean_row<C, QT, 2, 1>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane); break;
+        case 3: rowmean_row<C, QT, 2, 3>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane); break;
+        case 5: rowmean_row<C, QT, 2, 5>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane); break;
+        default: rowmean_row<C, QT, 2, 7>(qk, d, t, head_idx, n_heads, qk_scale, cost, lds[wave], lane); break;
+    }
 }
 
 // A SMALL batch (the reference's per-segment units: a handful of segments per 30 s window, any mix of lengths) is bound by
@@ -292,11 +317,24 @@ static int plan_groups(const ClassRange (&cls)[7], LaunchGroup (&g)[MAX_GROUPS],
 template <typename QT>
 static int launch_rowmean(const QT *qk, const wt_seg_desc *segs_dev, int n_seg, const LaunchGroup *groups, int n_groups,
                           bool grouped, const int32_t *head_idx, int n_heads, float qk_scale, float *cost,
-                          unsigned *segstate, hipStream_t st) {
+                          unsigned *segstate, hipStream_t st, int medfilt_width = 9) {
     for (int k = 0; k < n_groups; ++k) {
         const LaunchGroup &g = groups[k];
         const dim3 grid((g.maxT + 3) / 4, grouped ? g.n : n_seg);
         const int unit0 = grouped ? g.lo : 0;
+        if (medfilt_width != 9) {
+#define WT_LAUNCH_MEDW(CI)                                                                                            \
+    case CI:                                                                                                          \
+        hipLaunchKernelGGL((rowmean_medw_kernel<4 * (CI + 1), QT>), grid, dim3(256), 0, st, qk, segs_dev, head_idx, n_heads, \
+                           qk_scale, cost, segstate, unit0, g.f_lo, g.f_hi, medfilt_width);                            \
+        break;
+            switch (g.ci) {
+                WT_LAUNCH_MEDW(0) WT_LAUNCH_MEDW(1) WT_LAUNCH_MEDW(2) WT_LAUNCH_MEDW(3) WT_LAUNCH_MEDW(4) WT_LAUNCH_MEDW(5)
+                WT_LAUNCH_MEDW(6)
+            }
+#undef WT_LAUNCH_MEDW
+            continue;
+        }
 #define WT_LAUNCH_ROWMEAN(CI)                                                                                        \
     case CI:                                                                                                         \
         if (g.f_lo == CI * 256)                                                                                      \
@@ -329,8 +367,8 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
         return WT_E_BADARG;
     }
     if (n_seg == 0) return WT_OK;
-    if (medfilt_width != 9) {
-        set_error("wt_cost_batch: medfilt_width=%d unsupported (the reference always uses 9)", medfilt_width);
+    if (medfilt_width < 1 || medfilt_width > 9 || (medfilt_width & 1) == 0) {
+        set_error("wt_cost_batch: medfilt_width=%d unsupported (odd widths 1..9; the reference always uses 9)", medfilt_width);
         return WT_E_UNSUPPORTED;
     }
     if (!(qk_scale > 0.f)) {   // (the row maximum is taken before the scaling; the reference always passes 1.0)
@@ -358,7 +396,7 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     // token rows than two workgroups per CU hold at once; the bits are those of the per-class launches either way.
     long long total_rows = 0;
     for (int i = 0; i < n_seg; ++i) total_rows += segs_host[i].T;
-    if (!rows_per_class && total_rows <= 8LL * 256 * 2 && n_seg <= ANY_MAX_UNITS &&
+    if (!rows_per_class && medfilt_width == 9 && total_rows <= 8LL * 256 * 2 && n_seg <= ANY_MAX_UNITS &&
         (qk_dtype == WT_DTYPE_F32 || qk_dtype == WT_DTYPE_F16)) {
         WgTable table;
         unsigned n_wg = 0;
@@ -392,10 +430,10 @@ int cost_batch(const void *qk, int qk_dtype, const wt_seg_desc *segs_host, const
     // the groups are contiguous unit ranges when the classes are (sorted input); else fall back to full grids
     if (qk_dtype == WT_DTYPE_F32)
         rc = launch_rowmean((const float *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
-                            segstate, st);
+                            segstate, st, medfilt_width);
     else if (qk_dtype == WT_DTYPE_F16)
         rc = launch_rowmean((const __half *)qk, segs_dev, n_seg, groups, n_groups, grouped, head_idx, n_heads, qk_scale, cost,
-                            segstate, st);
+                            segstate, st, medfilt_width);
     else {
         set_error("wt_cost_batch: qk_dtype=%d", qk_dtype);
         return WT_E_BADARG;

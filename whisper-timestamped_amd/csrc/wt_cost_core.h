@@ -82,7 +82,30 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // waves hides the rest of the latency).  NB > 2 (small launches, where a wave's fetches are what the kernel waits for): the
 // rows of up to NB heads are fetched AT ONCE, one memory latency for all of them, then consumed one after the other.  The
 // arithmetic and the order of accumulation over heads are the same: same bits.
-template <int C, typename QT, int NB = 2>
+// median of the MW (odd, <= 9) values centred on v[4] of the nine v[0..8]: transcribe.py:1546 with medfilt_width = MW
+// (the reference's default and only caller value is 9; the other widths are the seam's parameter, transcribe.py:1439)
+template <int MW>
+__device__ __forceinline__ float median_window(const float *v);
+template <>
+__device__ __forceinline__ float median_window<1>(const float *v) { return v[4]; }
+template <>
+__device__ __forceinline__ float median_window<3>(const float *v) { return med3f(v[3], v[4], v[5]); }
+template <>
+__device__ __forceinline__ float median_window<5>(const float *v) {   // med3(e, max(min(a,b),min(c,d)), min(max(a,b),max(c,d)))
+    const float a = v[2], b = v[3], c = v[5], d = v[6], e = v[4];
+    return med3f(e, fmaxf(fminf(a, b), fminf(c, d)), fminf(fmaxf(a, b), fmaxf(c, d)));
+}
+template <>
+__device__ __forceinline__ float median_window<7>(const float *v) {   // 13 compare-exchanges (Devillard's opt_med7)
+    float p0 = v[1], p1 = v[2], p2 = v[3], p3 = v[4], p4 = v[5], p5 = v[6], p6 = v[7];
+#define WT_CX(a, b) { const float lo_ = fminf(a, b), hi_ = fmaxf(a, b); a = lo_; b = hi_; }
+    WT_CX(p0, p5) WT_CX(p0, p3) WT_CX(p1, p6) WT_CX(p2, p4) WT_CX(p0, p1) WT_CX(p3, p5) WT_CX(p2, p6)
+    WT_CX(p2, p3) WT_CX(p3, p6) WT_CX(p4, p5) WT_CX(p1, p4) WT_CX(p1, p3) WT_CX(p3, p4)
+#undef WT_CX
+    return p3;
+}
+
+template <int C, typename QT, int NB = 2, int MW = 9>
 __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride, const int32_t *__restrict__ head_idx,
                                              int n_heads, int F, float qk_scale, float (*lds)[RowBuf<C, QT>::BUF], int lane,
                                              f2 (&acc)[C / 2]) {
@@ -171,18 +194,24 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
     auto fold = [&](const float (&x)[C + 8]) __attribute__((always_inline)) {
         // median of 9 = med3(max3(lows), med3(mids), min3(highs)) over the sorted triples of 3 consecutive triples
         float lo[C + 6], mi[C + 6], hi[C + 6];
+        if constexpr (MW == 9) {
 #pragma unroll
-        for (int p = 0; p < C + 6; ++p) {
-            lo[p] = min3f(x[p], x[p + 1], x[p + 2]);
-            mi[p] = med3f(x[p], x[p + 1], x[p + 2]);
-            hi[p] = max3f(x[p], x[p + 1], x[p + 2]);
+            for (int p = 0; p < C + 6; ++p) {
+                lo[p] = min3f(x[p], x[p + 1], x[p + 2]);
+                mi[p] = med3f(x[p], x[p + 1], x[p + 2]);
+                hi[p] = max3f(x[p], x[p + 1], x[p + 2]);
+            }
         }
         float m[C];
         float mx = -1e30f;
 #pragma unroll
         for (int q = 0; q < C; ++q) {
-            const float med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
-                                    min3f(hi[q], hi[q + 3], hi[q + 6]));
+            float med;
+            if constexpr (MW == 9)
+                med = med3f(max3f(lo[q], lo[q + 3], lo[q + 6]), med3f(mi[q], mi[q + 3], mi[q + 6]),
+                            min3f(hi[q], hi[q + 3], hi[q + 6]));
+            else
+                med = median_window<MW>(&x[q]);            // (x[q + 4] is element q of this lane)
             const bool ok = (lane * C + q) < F;
             m[q] = ok ? med : -1e30f;
             mx = fmaxf(mx, m[q]);
