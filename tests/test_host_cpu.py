@@ -203,7 +203,8 @@ def test_c_abi_argument_validation_without_a_gpu():
     descs[0]["T"], descs[0]["F"] = 10, 100
     p = descs.ctypes.data
     assert L.wt_cost_batch(0, 0, p, p, 1, 0, 8, 9, 1.0, 0, 0) == -1 and b"null pointer" in L.wt_last_error()
-    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 7, 1.0, p, 0) == -3 and b"medfilt_width=7" in L.wt_last_error()
+    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 8, 1.0, p, 0) == -3 and b"medfilt_width=8" in L.wt_last_error()      # even
+    assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 11, 1.0, p, 0) == -3 and b"medfilt_width=11" in L.wt_last_error()    # > 9
     assert L.wt_cost_batch(p, 5, p, p, 0, p, 8, 9, 1.0, p, 0) == 0                     # n_seg == 0: nothing to do
     descs[0]["F"] = 5000
     assert L.wt_cost_batch(p, 0, p, p, 1, p, 8, 9, 1.0, p, 0) == -3 and b"unsupported shape" in L.wt_last_error()
