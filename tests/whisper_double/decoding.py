@@ -35,12 +35,12 @@ class Script:
         self._i = 0
         self.record.append([])
 
-    def pick(self, natural: int, logits_row=None, eot=None) -> int:
+    def pick(self, natural: int, logits_row=None, eot=None, text_best=None) -> int:
         tok = natural
         if self.windows is not None and self._k < len(self.windows) and self._i < len(self.windows[self._k]):
             tok = self.windows[self._k][self._i]
             if tok is None:       # "the most likely TEXT token": keeps the scripted structure, meaningful probabilities
-                tok = int(logits_row[:eot].argmax())
+                tok = int(logits_row[:eot].argmax()) if text_best is None else int(text_best)
         self._i += 1
         self.record[-1].append(int(tok))
         return int(tok)
@@ -188,7 +188,8 @@ class GreedyDecoder:
         if _ROW_SCRIPTS is not None:
             assert len(_ROW_SCRIPTS) == tokens.shape[0], (len(_ROW_SCRIPTS), tokens.shape)
             done = (tokens[:, -1] == self.eot).tolist()     # a finished row is fed eot from now on: its script is over
-            next_tokens = torch.tensor([int(t) if (sc is None or done[k]) else sc.pick(int(t), logits[k], self.eot)
+            best = logits[:, :self.eot].argmax(dim=-1).tolist()     # every row's most likely text token: one host read
+            next_tokens = torch.tensor([int(t) if (sc is None or done[k]) else sc.pick(int(t), None, self.eot, text_best=best[k])
                                         for k, (t, sc) in enumerate(zip(next_tokens.tolist(), _ROW_SCRIPTS))],
                                        device=logits.device)
         elif _SCRIPT is not None and tokens.shape[0] == 1:    # (several hypotheses: forced at the result level, see run())
