@@ -617,7 +617,10 @@ def run_e2e(dev, args, leg, emit):
         out = {"workload": f"whisper-{name} (random init, fp32), {n_per} x 30 s synthetic chunks per launch set, "
                            f"{len(transcripts[0])} window tokens in {len(E2E_SEGMENTS)} timestamped segments, teacher forced "
                            f"(naive strategy, trust_whisper_timestamps=False shape)", "chunks_per_launch": n_per,
-               "launch_sets": steps, "alignment_heads": len(heads)}
+               "launch_sets": steps, "alignment_heads": len(heads),
+               "what_this_leg_is": "the batched SECOND PASS of the naive strategy (naive_approach=True, trust_whisper_timestamps=False: "
+                                   "the transcript is given, the decoder is teacher forced) -- not what transcribe(model, audio) does "
+                                   "by default; that is the `default_strategy` object below"}
         res32, fp32 = timed(BatchedAligner(model, tokenizer, **opts))
         out.update(fp32)
         out["dtype"] = "f32 model (the CPU reference's arithmetic), f32 alignment, f64 DTW"
