@@ -1328,6 +1328,19 @@ def orchestrate(args):
             if e3:
                 eff["error"] = e3
             e2e["default_strategy"] = eff
+            # BASELINE configs[2]: whisper-small shapes through the same second pass (what the reference's beam-search
+            # path re-runs, teacher forced: transcribe.py:1197-1262), 32 chunks per launch set
+            small, e4 = run_child("e2e", ["--leg", "fp32", "--e2e-model", "small", "--no-cpu-baseline", "--e2e-steps", "3"], 300)
+            small = small or {}
+            if e4:
+                small["error"] = e4
+            half_s, e5 = run_child("e2e", ["--leg", "fp16", "--e2e-model", "small", "--e2e-steps", "3"], 300)
+            if half_s:
+                half_s.pop("marker", None)
+                small.update(half_s)
+            if e5:
+                small["fp16_legs_error"] = e5
+            e2e["whisper_small_shapes"] = small
             out["e2e"] = e2e
     print(json.dumps(out), flush=True)
     if out.get("value") is None:
