@@ -254,6 +254,80 @@ def test_islands_job_two_ranks_islands_as_decoder_streams(tmp_path):
     assert out.read_text().startswith("ok ")
 
 
+def _recordings_worker(rank, world, port, out_path):
+    """sharding.transcribe_recordings on two gloo ranks: the four same-model goldens dealt largest-first, each rank decodes
+    its share as decoder streams, rank 0 gets the four dictionaries in order -- each equal to the reference's output for
+    that recording."""
+    for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    patch = pytest.MonkeyPatch()
+    try:
+        import cpu_kernel_standin
+        import whisper_double as W
+        from golden import make_golden_transcribe as G
+        from test_streams_host import install_streams_standin, same_model_cases
+        from test_transcribe_host import compare, rounded
+        from whisper_double.decoding import Script, set_row_scripts
+        cpu_kernel_standin.install(patch)
+        install_streams_standin(patch)
+        W.install()
+        from whisper_timestamped import streams, words
+        from whisper_timestamped.sharding import transcribe_recordings
+        torch.set_num_threads(4)                    # (two ranks share the host's cores)
+        cases = same_model_cases()
+        model, _, _ = G.build_case(cases[0], device="cpu")
+        if rank != 0:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)                     # garbage until rank 0's weights arrive
+        audios = [G.build_case(c, device="cpu")[1] for c in cases]
+        seen = []
+
+        def on_batch(indices):
+            seen.extend(indices)
+            scripts = [Script(cases[i]["recorded"]) for i in indices]
+
+            def on_group(rows):
+                for r in rows:
+                    scripts[r].begin_window()
+                set_row_scripts([scripts[r] for r in rows])
+            streams.ON_GROUP_DECODE = on_group
+        words.RAW_CONFIDENCE = True
+        try:
+            results = transcribe_recordings(model, audios, dist=dist, broadcast_weights=True, streams=8, on_batch=on_batch,
+                                            fp16=False, **cases[0]["opts"])
+        finally:
+            words.RAW_CONFIDENCE = False
+            streams.ON_GROUP_DECODE = None
+            set_row_scripts(None)
+        owned = [None] * world
+        dist.all_gather_object(owned, seen)
+        assert sorted(i for part in owned for i in part) == list(range(4)) and all(len(part) > 0 for part in owned)
+        if rank == 0:
+            for r, c in zip(results, cases):
+                view = json.loads(json.dumps(G.public_view(r), default=float))
+                compare(rounded(view), c["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+            open(out_path, "w").write("ok " + repr(owned))
+        else:
+            assert results is None
+        dist.barrier()
+    finally:
+        patch.undo()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_recordings_across_two_ranks_streams_within_a_rank(tmp_path):
+    out = tmp_path / "recordings.txt"
+    mp.spawn(_recordings_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert out.read_text().startswith("ok ")
+
+
 def test_transcribe_many_two_worker_processes_on_the_cpu(monkeypatch):
     """sharding.transcribe_many's process plumbing (spawned workers, largest-first dealing, common start, results back in
     the caller's order) with the kernels replaced by the oracle-backed stand-in: the dictionaries of serial transcribe()

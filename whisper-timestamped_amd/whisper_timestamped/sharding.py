@@ -215,6 +215,46 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# Many recordings, many ranks: recordings across the GPUs, decoder streams within a GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def transcribe_recordings(model, audios, dist=None, broadcast_weights: bool = False, streams: int = 32, on_batch=None,
+                          **options):
+    """transcribe_timestamped() of every recording in `audios` on all ranks of `dist` (one process per GPU).  Recordings
+    are independent units: dealt to the ranks largest-first by length (`partition_units`), no data-path collective;
+    each rank steps ITS recordings through the decoder together, up to `streams` per decoder op (`transcribe_batch`);
+    rank 0 receives the result dictionaries with one object gather per job and returns them in the order of `audios`
+    (the other ranks return None).  Every rank passes the same `audios` list (paths, arrays or tensors; a rank only
+    loads its own).  `on_batch(indices)` is called on each rank with its recordings' indices, in stream order."""
+    from .naive import get_audio_tensor
+    from .transcribe import transcribe_batch
+    rank = 0 if dist is None else dist.get_rank()
+    world = 1 if dist is None else dist.get_world_size()
+    audios = list(audios)
+    if world > 1 and broadcast_weights:
+        broadcast_module_weights(dist, model, src=0)
+
+    def length(a):
+        if isinstance(a, str):
+            import os
+            return os.path.getsize(a)            # (a proxy: compressed files of one codec scale with their duration)
+        return int(a.shape[-1])
+    parts = partition_units([length(a) for a in audios], world)
+    idx = list(parts[rank])
+    if on_batch is not None:
+        on_batch(idx)
+    mine = list(zip(idx, transcribe_batch(model, [get_audio_tensor(audios[i]) for i in idx], max_streams=streams, **options)))
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank != 0:
+            return None
+        mine = [x for part in gathered for x in part]
+    by_index = dict(mine)
+    assert sorted(by_index) == list(range(len(audios)))
+    return [by_index[i] for i in range(len(audios))]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # Many recordings, several worker processes per GPU
 # ----------------------------------------------------------------------------------------------------------------------
 # The default (efficient) strategy decodes ONE stream token by token inside the ASR backend's own Python loop
