@@ -59,16 +59,13 @@ def run_batch(cases, device="cpu", raw_confidence=True, max_streams=32, **extra)
         set_row_scripts([scripts[base[0] + i] for i in idx])
     set_script(None)
     streams.ON_GROUP_DECODE = on_group
+    streams.ON_CHUNK_START = lambda i0: base.__setitem__(0, i0)     # (the driver numbers streams per chunk of max_streams)
     words.RAW_CONFIDENCE = bool(raw_confidence)
     try:
-        results = []
-        for a in range(0, len(audios), max_streams):     # (the driver numbers streams per chunk of max_streams)
-            base[0] = a
-            results += wt.transcribe_batch(model, audios[a:a + max_streams], fp16=False, max_streams=max_streams,
-                                           **cases[0]["opts"], **extra)
+        results = wt.transcribe_batch(model, audios, fp16=False, max_streams=max_streams, **cases[0]["opts"], **extra)
     finally:
         words.RAW_CONFIDENCE = False
-        streams.ON_GROUP_DECODE = None
+        streams.ON_GROUP_DECODE = streams.ON_CHUNK_START = None
         set_row_scripts(None)
     for c, sc in zip(cases, scripts):
         assert sc.record == c["recorded"], c["name"]

@@ -47,7 +47,9 @@ from .words import HOP_LENGTH, N_FRAMES, SAMPLE_RATE
 logger = logging.getLogger("whisper_timestamped")
 
 N_SAMPLES = 30 * SAMPLE_RATE
-# test / instrumentation seam: called with the stream indices of a batched decoder loop right before it starts
+# test / instrumentation seams: ON_CHUNK_START(i0) before recordings i0 .. i0 + max_streams - 1 are taken up (streams are
+# numbered from 0 inside a chunk), ON_GROUP_DECODE(stream indices) right before a batched decoder loop starts
+ON_CHUNK_START = None
 ON_GROUP_DECODE = None
 LAST_RUN = {}
 
@@ -512,6 +514,8 @@ def transcribe_efficient_streams(model, audios, *, remove_punctuation_from_words
     assert supports(whisper_options, plot_word_alignment=plot_word_alignment)
     out = []
     for a in range(0, len(audios), max_streams):
+        if ON_CHUNK_START is not None:
+            ON_CHUNK_START(a)
         out.extend(_run_streams(model, audios[a:a + max_streams], dict(whisper_options),
                                 remove_punctuation_from_words=remove_punctuation_from_words,
                                 compute_word_confidence=compute_word_confidence,
