@@ -102,6 +102,19 @@ def test_streams_of_different_lengths_each_equal_the_reference(monkeypatch):
     assert streams.LAST_RUN["alignment_launch_sets"] <= streams.LAST_RUN["rounds"] + 1
 
 
+def test_language_detection_for_every_stream_in_one_call(monkeypatch):
+    """language=None: the backend's detect_language runs ONCE for all streams (one (B, 1) decoder call), every stream's
+    session sees it as its own hooks would have (language probabilities, the no-speech probability the reference
+    takes from that call) -- two streams, each equal to the reference's output for the recording."""
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    case = next(c for c in CASES if c["name"] == "language_detection")
+    cases = [copy.deepcopy(case), copy.deepcopy(case)]
+    for raw in run_batch(cases):
+        compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+        assert "language_probs_top" in raw and raw["language"] == case["expected"]["language"]
+
+
 def test_more_recordings_than_streams(monkeypatch):
     cpu_kernel_standin.install(monkeypatch)
     install_streams_standin(monkeypatch)
