@@ -138,6 +138,11 @@ def test_calls_the_batched_path_cannot_take_run_one_by_one(monkeypatch):
     with pytest.raises(AssertionError, match="unknown options"):
         wt.transcribe_batch(None, [torch.zeros(16000)], not_an_option=1)
     assert wt.transcribe_batch(None, []) == []
+    assert streams.backend_missing() == []                       # the double has openai-whisper's DecodingTask surface
+    real = W.decoding.DecodingTask._main_loop
+    monkeypatch.delattr(W.decoding.DecodingTask, "_main_loop")
+    assert streams.backend_missing() == ["DecodingTask._main_loop"]
+    monkeypatch.setattr(W.decoding.DecodingTask, "_main_loop", real, raising=False)
 
 
 def test_batched_timestamp_rules_equal_the_backends_row_by_row(monkeypatch):

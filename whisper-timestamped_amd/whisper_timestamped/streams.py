@@ -472,6 +472,23 @@ def supports(whisper_options, vad=None, naive_approach=False, plot_word_alignmen
                 whisper_options.get("beam_size") is not None or (whisper_options.get("best_of") or 1) > 1)
 
 
+def backend_missing():
+    """What the B-stream driver needs of the ASR backend beyond what the one-stream path uses: openai-whisper's
+    DecodingTask with its decoder loop as a method of its own (whisper/decoding.py: `_main_loop(audio_features, tokens)`,
+    `_get_audio_features(mel)`, `initial_tokens`, `sample_begin`, `decoder.finalize`, `logit_filters`).  -> list of what is
+    missing ([] = fine); transcribe_batch then decodes the recordings one stream at a time instead."""
+    w = backend.whisper()
+    task = getattr(getattr(w, "decoding", None), "DecodingTask", None)
+    if task is None:
+        return ["whisper.decoding.DecodingTask"]
+    missing = [f"DecodingTask.{m}" for m in ("_main_loop", "_get_audio_features", "_get_initial_tokens") if not hasattr(task, m)]
+    if not hasattr(w, "DecodingOptions"):
+        missing.append("whisper.DecodingOptions")
+    if not hasattr(getattr(w, "utils", None), "compression_ratio"):
+        missing.append("whisper.utils.compression_ratio")
+    return missing
+
+
 def _whole_file_mels(model, audios, dtype):
     """Every recording's log-mel over the whole file + 30 s of silence, file-global max clamp (whisper's transcribe():
     log_mel_spectrogram(audio, n_mels, padding=N_SAMPLES)) on the GPU; recordings of equal length share a launch."""

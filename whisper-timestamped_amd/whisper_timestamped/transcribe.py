@@ -279,6 +279,10 @@ def transcribe_batch(model, audios, max_streams=32, **options):
     from . import streams
     if not streams.supports(plan["whisper_options"], plan["vad"], plan["naive_approach"], a["plot_word_alignment"]):
         return [transcribe_timestamped(model, audio, **options) for audio in audios]
+    missing = streams.backend_missing()
+    if missing:
+        logger.warning(f"transcribe_batch: this ASR backend lacks {', '.join(missing)}: decoding one stream at a time")
+        return [transcribe_timestamped(model, audio, **options) for audio in audios]
     if a["seed"] is not None:
         torch.manual_seed(a["seed"])
         torch.cuda.manual_seed_all(a["seed"])
