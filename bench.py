@@ -1140,37 +1140,44 @@ def run_efficient_leg(args, emit):
     #      silero itself needs network), every island an independent unit -> the rank's islands as decoder streams.  On N
     #      ranks the same call deals the islands to the ranks first (sharding.transcribe_islands, no data-path collective).
     from whisper_timestamped.sharding import transcribe_islands
-    n_islands = 120
-    hour = torch.cat([clips[k % len(clips)] for k in range(n_islands)])
-    islands = [(30.0 * k, 30.0 * (k + 1)) for k in range(n_islands)]
+    pattern = (90, 30, 30, 60, 30, 60)                      # island lengths in seconds: one to three 30 s windows each
+    durations = [pattern[k % len(pattern)] for k in range(72)]          # 12 x 300 s = one hour
+    assert sum(durations) == 3600
+    hour = torch.cat([clips[k % len(clips)] for k in range(120)])
+    islands, t = [], 0.0
+    for d_ in durations:
+        islands.append((t, t + d_))
+        t += d_
 
     def on_batch(indices):
-        scripts = [Script([window]) for _ in indices]
-        base = [0]
+        scripts = [Script([window] * (durations[i] // 30)) for i in indices]
 
-        def on_group(rows):
+        def on_group(rows):                              # rows: positions in the rank's list of islands
             for r in rows:
-                scripts[base[0] + r].begin_window()
-            set_row_scripts([scripts[base[0] + r] for r in rows])
-        streams.ON_CHUNK_START = lambda i0: base.__setitem__(0, i0)      # (streams are numbered from 0 inside a chunk)
+                scripts[r].begin_window()
+            set_row_scripts([scripts[r] for r in rows])
         streams.ON_GROUP_DECODE = on_group
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     try:
         merged = transcribe_islands(model, hour, islands, streams=B, on_batch=on_batch, language="en", fp16=False)
     finally:
-        streams.ON_GROUP_DECODE = streams.ON_CHUNK_START = None
+        streams.ON_GROUP_DECODE = None
         set_row_scripts(None)
     torch.cuda.synchronize()
     el_h = time.perf_counter() - t0
-    first = words_of(singles[0])
-    got0 = [(w["text"], w["start"], w["end"], w["confidence"]) for s_ in merged["segments"][:len(singles[0]["segments"])] for w in s_["words"]]
-    assert [x[0] for x in got0] == [x[0] for x in first] and all(abs(x[1] - y[1]) <= 0.02 + 1e-9 for x, y in zip(got0, first))
-    out["long_form_1h_islands"] = {"audio_s_per_s": round(3600.0 / el_h, 1), "seconds": round(el_h, 3), "islands": n_islands,
-                                   "streams_per_decoder_op": B, "segments": len(merged["segments"]),
+    n_windows = sum(d_ // 30 for d_ in durations)
+    assert len(merged["segments"]) == 5 * n_windows, (len(merged["segments"]), n_windows)
+    starts = [s_["start"] for s_ in merged["segments"]]
+    assert starts == sorted(starts) and all(len(s_["words"]) > 0 for s_ in merged["segments"])
+    out["long_form_1h_islands"] = {"audio_s_per_s": round(3600.0 / el_h, 1), "seconds": round(el_h, 3), "islands": len(islands),
+                                   "island_seconds": "30 / 60 / 90 (one to three windows each)", "windows": n_windows,
+                                   "streams_per_decoder_op": B, "driver": dict(streams.LAST_RUN),
+                                   "segments": len(merged["segments"]),
                                    "words": sum(len(s_["words"]) for s_ in merged["segments"]),
                                    "note": "BASELINE configs[3] at N = 1: explicit speech islands of one 1 h recording "
-                                           "(sharding.transcribe_islands(streams=B)); on N ranks the islands are dealt to the ranks first"}
+                                           "(sharding.transcribe_islands(streams=B)): an island that is finished hands its "
+                                           "place to the next one; on N ranks the islands are dealt to the ranks first"}
     emit(out)
 
     # ---- the reference-shaped CPU path, same clips (bounded sample)

@@ -157,12 +157,11 @@ def _run_islands_job(dist, job, patch, device="cpu", streams=0):
     def on_batch(indices):                           # streams: one script per island, routed to its row of every decoder loop
         seen.extend(indices)
         scripts = [Script(job["recorded"][i]) for i in indices]
-        base = [0]
 
-        def on_group(rows):
+        def on_group(rows):                              # rows: positions in this rank's list of islands
             for r in rows:
-                scripts[base[0] + r].begin_window()
-            set_row_scripts([scripts[base[0] + r] for r in rows])     # (streams >= islands per rank here: one chunk)
+                scripts[r].begin_window()
+            set_row_scripts([scripts[r] for r in rows])
         streams_mod.ON_GROUP_DECODE = on_group
     try:
         result = transcribe_islands(model, audio, job["islands"], dist=dist, broadcast_weights=True, on_island=on_island,

@@ -51,21 +51,19 @@ def run_batch(cases, device="cpu", raw_confidence=True, max_streams=32, **extra)
         model = model or m
         audios.append(audio)
     scripts = [Script(c["recorded"]) for c in cases]
-    base = [0]
 
-    def on_group(idx):
+    def on_group(idx):                                   # idx: the recordings of this decoder loop, in row order
         for i in idx:
-            scripts[base[0] + i].begin_window()
-        set_row_scripts([scripts[base[0] + i] for i in idx])
+            scripts[i].begin_window()
+        set_row_scripts([scripts[i] for i in idx])
     set_script(None)
     streams.ON_GROUP_DECODE = on_group
-    streams.ON_CHUNK_START = lambda i0: base.__setitem__(0, i0)     # (the driver numbers streams per chunk of max_streams)
     words.RAW_CONFIDENCE = bool(raw_confidence)
     try:
         results = wt.transcribe_batch(model, audios, fp16=False, max_streams=max_streams, **cases[0]["opts"], **extra)
     finally:
         words.RAW_CONFIDENCE = False
-        streams.ON_GROUP_DECODE = streams.ON_CHUNK_START = None
+        streams.ON_GROUP_DECODE = None
         set_row_scripts(None)
     for c, sc in zip(cases, scripts):
         assert sc.record == c["recorded"], c["name"]
@@ -116,12 +114,19 @@ def test_language_detection_for_every_stream_in_one_call(monkeypatch):
 
 
 def test_more_recordings_than_streams(monkeypatch):
+    """Continuous admission: fewer ring blocks than recordings -- a recording that is finished hands its block to the next
+    one while the others go on (their tails are flushed before the block is overwritten).  Eight ragged recordings through
+    two and through three blocks: each equals the reference's output for it."""
+    from whisper_timestamped import streams
     cpu_kernel_standin.install(monkeypatch)
     install_streams_standin(monkeypatch)
-    cases = same_model_cases()
-    views = run_batch(cases, max_streams=3)
-    for raw, case in zip(views, cases):
-        compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+    for n_blocks in (2, 3):
+        cases = same_model_cases() + same_model_cases()[::-1]
+        views = run_batch(cases, max_streams=n_blocks)
+        for raw, case in zip(views, cases):
+            compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+        assert streams.LAST_RUN["ring_blocks"] == n_blocks and streams.LAST_RUN["streams"] == 8
+        assert streams.LAST_RUN["admissions"] >= 3                    # blocks were handed on, more than once
 
 
 def test_calls_the_batched_path_cannot_take_run_one_by_one(monkeypatch):

@@ -47,9 +47,8 @@ from .words import HOP_LENGTH, N_FRAMES, SAMPLE_RATE
 logger = logging.getLogger("whisper_timestamped")
 
 N_SAMPLES = 30 * SAMPLE_RATE
-# test / instrumentation seams: ON_CHUNK_START(i0) before recordings i0 .. i0 + max_streams - 1 are taken up (streams are
-# numbered from 0 inside a chunk), ON_GROUP_DECODE(stream indices) right before a batched decoder loop starts
-ON_CHUNK_START = None
+# test / instrumentation seam: called with the RECORDING indices (positions in `audios`) of the streams of a batched decoder
+# loop, in row order, right before it starts
 ON_GROUP_DECODE = None
 LAST_RUN = {}
 
@@ -382,14 +381,15 @@ class _Stream:
         self.n_initial_prompt = len(initial_prompt_tokens)
         self.all_segments = []
         self.prompt_reset_since = 0
-        self.done = content_frames <= 0
+        self.done = False
+        self.block = index                  # its block of the shared rings (the driver assigns it on admission)
         # the window being decoded
         self.segment_size = 0
         self.task = None
         self.initial_tokens = None
 
     def active(self):
-        return not self.done and self.seek < self.content_frames
+        return not self.done and self.content_frames > 0 and self.seek < self.content_frames
 
     def window_mel(self):
         self.segment_size = min(N_FRAMES, self.content_frames - self.seek)
@@ -526,29 +526,27 @@ def transcribe_efficient_streams(model, audios, *, remove_punctuation_from_words
                                  plot_word_alignment, word_alignment_most_top_layers, detect_disfluencies,
                                  trust_whisper_timestamps, use_timestamps_for_alignment=True, max_streams=32,
                                  **whisper_options):
-    """``[transcribe_efficient(model, a, ...) for a in audios]`` with the recordings decoded ``max_streams`` at a time.
-    Returns a list of (transcription, words), one per recording, in order."""
+    """``[transcribe_efficient(model, a, ...) for a in audios]`` with up to ``max_streams`` recordings stepping through
+    the decoder together; a recording that is finished hands its place to the next one (continuous admission: short and
+    long recordings mix without the long ones ending up alone).  Returns a list of (transcription, words), one per
+    recording, in order."""
     assert supports(whisper_options, plot_word_alignment=plot_word_alignment)
-    out = []
-    for a in range(0, len(audios), max_streams):
-        if ON_CHUNK_START is not None:
-            ON_CHUNK_START(a)
-        out.extend(_run_streams(model, audios[a:a + max_streams], dict(whisper_options),
-                                remove_punctuation_from_words=remove_punctuation_from_words,
-                                compute_word_confidence=compute_word_confidence,
-                                include_punctuation_in_confidence=include_punctuation_in_confidence,
-                                refine_whisper_precision_nframes=refine_whisper_precision_nframes,
-                                alignment_heads=alignment_heads, word_alignment_most_top_layers=word_alignment_most_top_layers,
-                                detect_disfluencies=detect_disfluencies, trust_whisper_timestamps=trust_whisper_timestamps,
-                                use_timestamps_for_alignment=use_timestamps_for_alignment))
-    return out
+    return _run_streams(model, list(audios), dict(whisper_options), max(1, int(max_streams)),
+                        remove_punctuation_from_words=remove_punctuation_from_words,
+                        compute_word_confidence=compute_word_confidence,
+                        include_punctuation_in_confidence=include_punctuation_in_confidence,
+                        refine_whisper_precision_nframes=refine_whisper_precision_nframes,
+                        alignment_heads=alignment_heads, word_alignment_most_top_layers=word_alignment_most_top_layers,
+                        detect_disfluencies=detect_disfluencies, trust_whisper_timestamps=trust_whisper_timestamps,
+                        use_timestamps_for_alignment=use_timestamps_for_alignment)
 
 
-def _run_streams(model, audios, opts, **session_kwargs):
+def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     w = backend.whisper()
     dev = model.device
     _lib.require_gpu(dev)
-    B = len(audios)
+    N = len(audios)
+    S = min(N, max_streams)                               # ring blocks = recordings in flight
     opts["verbose"] = None
     fp16 = bool(opts.get("fp16"))
     dtype = torch.float16 if fp16 else torch.float32
@@ -560,20 +558,33 @@ def _run_streams(model, audios, opts, **session_kwargs):
     top_layers = session_kwargs["word_alignment_most_top_layers"]
     top = n_blocks if top_layers is None else min(top_layers, n_blocks)
     hooked_blocks = list(range(n_blocks - top, n_blocks))
-    rings = StreamRings(model, session_kwargs["alignment_heads"], hooked_blocks, B, efficient.RING_DTYPE)
+    rings = StreamRings(model, session_kwargs["alignment_heads"], hooked_blocks, S, efficient.RING_DTYPE)
     sink = _Sink(default_workspace(dev))
-    mels = _whole_file_mels(model, audios, dtype)
+    streams = [None] * N                                  # by recording
+    free = list(range(S))
+    pending = list(range(N))
+    admissions = 0
 
-    with torch.no_grad():
-        # ---- language (whisper's transcribe(): detect on the first 30 s when not given), one batched call
-        languages = [opts["language"]] * B
+    def admit():
+        """Pending recordings into the free ring blocks: their whole-file log-mels (one launch per length), their
+        language (one batched detect_language call), their sessions on views of their blocks."""
+        nonlocal admissions
+        new = []
+        while free and pending:
+            new.append((pending.pop(0), free.pop(0)))
+        if not new:
+            return
+        admissions += 1
+        mels = _whole_file_mels(model, [audios[i] for i, _ in new], dtype)
+        languages = [opts["language"]] * len(new)
         lang_events = None
-        if opts["language"] is None:
+        if opts["language"] is None:                      # whisper's transcribe(): detect on the first 30 s when not given
             if not model.is_multilingual:
-                languages = ["en"] * B
+                languages = ["en"] * len(new)
             else:
                 first = torch.stack([torch.nn.functional.pad(m[:, :N_FRAMES], (0, max(0, N_FRAMES - m.shape[-1]))) for m in mels])
-                rec = _Recorder(model, rings, hooked_blocks, torch.arange(B, dtype=torch.int32, device=dev), verify=False)
+                rec = _Recorder(model, rings, hooked_blocks, torch.tensor([b for _, b in new], dtype=torch.int32, device=dev),
+                                verify=False)
                 rec.capture = False
                 rec.install()
                 try:
@@ -582,77 +593,90 @@ def _run_streams(model, audios, opts, **session_kwargs):
                     rec.remove()
                 languages = [max(p, key=p.get) for p in probs]
                 lang_events = (first, rec.calls[0], rec.first_outs, _lib.HostCopy(_lib.find_start_padding(first.float())))
-
-        streams = []
-        for i in range(B):
-            s_opts = dict(opts)
-            session = EfficientSession(model, s_opts, ring=_QKView(rings.qk[i]), logits=_LogitsView(rings.logits[i]), sink=sink,
-                                       **session_kwargs)
-            tk = backend.get_tokenizer(model, task=opts["task"], language=languages[i])
+        for j, ((i, block), mel, lang) in enumerate(zip(new, mels, languages)):
+            session = EfficientSession(model, dict(opts), ring=_QKView(rings.qk[block]), logits=_LogitsView(rings.logits[block]),
+                                       sink=sink, **session_kwargs)
+            tk = backend.get_tokenizer(model, task=opts["task"], language=lang)
             prompt0 = tk.encode(" " + opts["initial_prompt"].strip()) if opts.get("initial_prompt") is not None else []
-            streams.append(_Stream(i, mels[i], mels[i].shape[-1] - N_FRAMES, session, tk, languages[i], prompt0))
-        if lang_events is not None:                       # the language-detection call, as every stream's hooks saw it
-            first, calls, outs, pad0 = lang_events
-            for s in streams:
-                m = first[s.index:s.index + 1]
-                s.session.hook_mel(None, (m,), None, pad_handle=_SliceOfCopy(pad0, s.index))
-                s.session.on_tokens(list(calls[s.index]))
-                s.session.hook_decoder_logits(None, None, outs[s.index:s.index + 1])
+            st = streams[i] = _Stream(i, mel, mel.shape[-1] - N_FRAMES, session, tk, lang, prompt0)
+            st.block = block
+            if lang_events is not None:                   # the language-detection call, as this stream's hooks saw it
+                first, calls, outs, pad0 = lang_events
+                session.hook_mel(None, (first[j:j + 1],), None, pad_handle=_SliceOfCopy(pad0, j))
+                session.on_tokens(list(calls[j]))
+                session.hook_decoder_logits(None, None, outs[j:j + 1])
 
-        rounds = groups = 0
-        verify = efficient.REUSE_DECODER_LOGITS == "auto"
-        fused_checked = False
+    def retire(st):
+        """The backend would return now: the stream's last window is flushed and closed (its units wait in the sink for
+        the next launch set, which is queued BEFORE anything can overwrite its ring block), the block is free."""
+        st.session.end_of_stream()
+        st.done = True
+        st.mel = None
+        free.append(st.block)
+
+    rounds = groups = 0
+    verify = efficient.REUSE_DECODER_LOGITS == "auto"
+    fused_checked = False
+    with torch.no_grad():
         while True:
-            act = [s for s in streams if s.active()]
+            admit()
+            for st in streams:                            # (recordings with nothing to decode: empty audio)
+                if st is not None and not st.done and not st.active():
+                    retire(st)
+            act = [st for st in streams if st is not None and st.active()]
             if not act:
+                if pending:
+                    continue
                 break
             rounds += 1
             # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
-            mel_batch = torch.stack([s.window_mel() for s in act]).to(dtype)
+            mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
             pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
-            for j, s in enumerate(act):
+            for j, st in enumerate(act):
                 kwargs = {k: opts[k] for k in decode_keys if k in opts}
-                kwargs["language"] = s.language
-                kwargs["prompt"] = s.all_tokens[s.prompt_reset_since:]
+                kwargs["language"] = st.language
+                kwargs["prompt"] = st.all_tokens[st.prompt_reset_since:]
                 if temperature > 0:
                     kwargs.pop("beam_size", None), kwargs.pop("patience", None)
                 else:
                     kwargs.pop("best_of", None)
-                s.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
-                s.initial_tokens = list(s.task.initial_tokens)
-                s.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
-                s.session.on_tokens(list(s.initial_tokens))
+                st.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
+                st.initial_tokens = list(st.task.initial_tokens)
+                st.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
+                st.session.on_tokens(list(st.initial_tokens))
             sink.launch()
             # ---- one batched decoder loop per initial-token length
             by_len = {}
-            for j, s in enumerate(act):
-                by_len.setdefault(len(s.initial_tokens), []).append(j)
+            for j, st in enumerate(act):
+                by_len.setdefault(len(st.initial_tokens), []).append(j)
             for L, members in by_len.items():
                 groups += 1
                 grp = [act[j] for j in members]
                 if ON_GROUP_DECODE is not None:
-                    ON_GROUP_DECODE([s.index for s in grp])
+                    ON_GROUP_DECODE([st.index for st in grp])
                 task = vectorize_filters(grp[0].task)
-                ring_index = torch.tensor([s.index for s in grp], dtype=torch.int32, device=dev)
+                ring_index = torch.tensor([st.block for st in grp], dtype=torch.int32, device=dev)
                 rec = _Recorder(model, rings, hooked_blocks, ring_index, verify=verify)
                 rec.fused_checked = fused_checked or not efficient.FUSED_ATTENTION
                 task.decoder.reset()
                 rec.install()
                 try:
                     feats = task._get_audio_features(mel_batch[members])
-                    tokens0 = torch.tensor([s.initial_tokens for s in grp], device=dev)
+                    tokens0 = torch.tensor([st.initial_tokens for st in grp], device=dev)
                     tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
                     rec.commit()
                 finally:
                     rec.remove()
                 fused_checked = True
                 _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify)
-        for s in streams:
-            s.session.end_of_stream()
+            for st in act:                                # finished recordings hand their blocks to the next ones
+                if not st.active():
+                    retire(st)
         sink.resolve()
-        out = [s.session.compiled(s.transcription()) for s in streams]
+        out = [st.session.compiled(st.transcription()) for st in streams]
     LAST_RUN.clear()
-    LAST_RUN.update(streams=B, rounds=rounds, decoder_loops=groups, alignment_launch_sets=sink.launch_sets)
+    LAST_RUN.update(streams=N, ring_blocks=S, admissions=admissions, rounds=rounds, decoder_loops=groups,
+                    alignment_launch_sets=sink.launch_sets)
     return out
 
 
@@ -698,7 +722,7 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
                                "re-projected ones); use the one-stream path")
     # ONE gather for every (stream, call): log_softmax(row)[sampled token]
     cap1 = rings.logits.shape[1]
-    row_index = torch.tensor([int(s.index) * cap1 + k for i, s in enumerate(grp) for k in range(len(sampled[i]))], dtype=torch.int32)
+    row_index = torch.tensor([int(s.block) * cap1 + k for i, s in enumerate(grp) for k in range(len(sampled[i]))], dtype=torch.int32)
     tok = torch.tensor([t for smp in sampled for t in smp], dtype=torch.int32)
     flat = rings.logits.view(-1, rings.logits.shape[-1])
     lps = _lib.logprob_gather_rows(flat, row_index.to(flat.device), tok.to(flat.device)).cpu().numpy()
@@ -712,7 +736,7 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         ses = s.session
         assert rec.calls[0][i] == s.initial_tokens
         ses.hook_decoder_logits(None, None, rec.first_outs[i:i + 1])
-        view = rings.logits[s.index]
+        view = rings.logits[s.block]
         for k in range(1, len(sampled[i])):
             ses.on_tokens(rec.calls[k][i])
             ses.hook_decoder_logits(None, None, view[k:k + 1].unsqueeze(0))
