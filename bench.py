@@ -1157,28 +1157,34 @@ def run_efficient_leg(args, emit):
                 scripts[r].begin_window()
             set_row_scripts([scripts[r] for r in rows])
         streams.ON_GROUP_DECODE = on_group
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    try:
-        merged = transcribe_islands(model, hour, islands, streams=B, on_batch=on_batch, language="en", fp16=False)
-    finally:
-        streams.ON_GROUP_DECODE = None
-        set_row_scripts(None)
-    torch.cuda.synchronize()
-    el_h = time.perf_counter() - t0
     n_windows = sum(d_ // 30 for d_ in durations)
-    assert len(merged["segments"]) == 5 * n_windows, (len(merged["segments"]), n_windows)
-    starts = [s_["start"] for s_ in merged["segments"]]
-    assert starts == sorted(starts) and all(len(s_["words"]) > 0 for s_ in merged["segments"])
-    out["long_form_1h_islands"] = {"audio_s_per_s": round(3600.0 / el_h, 1), "seconds": round(el_h, 3), "islands": len(islands),
-                                   "island_seconds": "30 / 60 / 90 (one to three windows each)", "windows": n_windows,
-                                   "streams_per_decoder_op": B, "driver": dict(streams.LAST_RUN),
-                                   "segments": len(merged["segments"]),
-                                   "words": sum(len(s_["words"]) for s_ in merged["segments"]),
-                                   "note": "BASELINE configs[3] at N = 1: explicit speech islands of one 1 h recording "
-                                           "(sharding.transcribe_islands(streams=B)): an island that is finished hands its "
-                                           "place to the next one; on N ranks the islands are dealt to the ranks first"}
-    emit(out)
+    out["long_form_1h_islands"] = {
+        "islands": len(islands), "island_seconds": "30 / 60 / 90 (one to three windows each)", "windows": n_windows,
+        "streams_per_decoder_op": B,
+        "note": "BASELINE configs[3] at N = 1: explicit speech islands of one 1 h recording (sharding.transcribe_islands("
+                "streams=B)): an island that is finished hands its place to the next one; on N ranks the islands are dealt to "
+                "the ranks first.  Streams share a decoder loop only when their prompts have the same LENGTH (the decoder has no "
+                "padding mask: padding would move the positions and change the result): with the reference's default "
+                "condition_on_previous_text=True the later windows of a recording form their own loops until the prompt "
+                "saturates at 223 tokens; without conditioning every round is one loop"}
+    for label, cond in (("condition_on_previous_text", True), ("no_condition", False)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            merged = transcribe_islands(model, hour, islands, streams=B, on_batch=on_batch, language="en", fp16=False,
+                                        condition_on_previous_text=cond)
+        finally:
+            streams.ON_GROUP_DECODE = None
+            set_row_scripts(None)
+        torch.cuda.synchronize()
+        el_h = time.perf_counter() - t0
+        assert len(merged["segments"]) == 5 * n_windows, (len(merged["segments"]), n_windows)
+        starts = [s_["start"] for s_ in merged["segments"]]
+        assert starts == sorted(starts) and all(len(s_["words"]) > 0 for s_ in merged["segments"])
+        out["long_form_1h_islands"][label] = {"audio_s_per_s": round(3600.0 / el_h, 1), "seconds": round(el_h, 3),
+                                              "driver": dict(streams.LAST_RUN), "segments": len(merged["segments"]),
+                                              "words": sum(len(s_["words"]) for s_ in merged["segments"])}
+        emit(out)
 
     # ---- the reference-shaped CPU path, same clips (bounded sample)
     if not args.no_cpu_baseline:

@@ -28,6 +28,14 @@ stream's prompt call replayed (previous window flushed and closed, its units que
 the batched decoder loops (which overwrite the rings: the kernels that read the old rows are already queued on the
 same HIP stream) -> the remaining recorded calls replayed.
 
+Which streams share a decoder loop: those whose initial-token rows have the same LENGTH (the backend's decoder has no
+padding mask; padding a shorter prompt would move every position and change the result).  Recordings of <= 30 s
+(BASELINE configs[1]), first windows, unconditioned decoding (condition_on_previous_text=False) and saturated prompts
+(223 tokens, after two or three dense windows) all meet in one loop per round; with the reference's default
+conditioning the second / third windows of a recording carry prompts of their own lengths and form small loops of
+their own -- correct, less batched.  A recording that is finished hands its ring block to the next one (continuous
+admission), so short and long recordings mix without the long ones ending up alone.
+
 Results: for a given stream the host logic is byte for byte the B = 1 code; the numerics differ from a B = 1 run only
 through the batch size of the backend's GEMMs (tests: B = 8 equals eight B = 1 runs word for word, time for time).
 """
