@@ -187,3 +187,76 @@ def test_batched_timestamp_rules_equal_the_backends_row_by_row(monkeypatch):
             mine.apply(b, tokens)
             assert torch.equal(torch.isinf(a), torch.isinf(b)), (sample_begin, n)
             assert torch.equal(a, b), (sample_begin, n)
+
+
+def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
+    """streams._Stream.take_result restates what the backend's transcribe() loop does with the DecodingResult of a window
+    (no-speech skip, segments at consecutive timestamps, seek, prompt bookkeeping).  The one-stream path runs the
+    backend's own loop, the B-stream path this restatement: held against each other on random results -- no timestamps at
+    all, single timestamps, pairs, every ending, empty results, no-speech windows -- through the backend's loop with a
+    model whose decode() returns the scripted results."""
+    import types
+
+    import numpy as np
+    import whisper_double as W
+    from whisper_timestamped import streams
+    W.install()
+    tk = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    ts0, eot = tk.timestamp_begin, tk.eot
+    rng = np.random.RandomState(17)
+
+    def random_result():
+        kind = rng.randint(7)
+        toks, t = [], int(rng.randint(0, 200))
+        text = lambda n: [int(x) for x in rng.randint(300, 20000, size=n)]      # noqa: E731
+        if kind == 0:
+            toks = text(rng.randint(0, 12))                                     # no timestamps (or nothing at all)
+        elif kind == 1:
+            toks = [ts0 + t] + text(rng.randint(1, 9))                          # a start, no end
+        else:
+            for _ in range(rng.randint(1, 5)):
+                e = t + int(rng.randint(1, 300))
+                toks += [ts0 + t] + text(rng.randint(0, 8)) + [ts0 + min(e, 1500)]
+                t = min(e + int(rng.randint(0, 30)), 1500)
+            if kind == 2:
+                toks = toks[:-1]                                                # the last segment has no closing timestamp
+            elif kind == 3:
+                toks.append(toks[-1])                                           # ... <|e|><|e|>: "no speech after"
+            elif kind == 4:
+                toks += [ts0 + t] + text(3)                                     # an open segment after the pairs
+        return W.DecodingResult(audio_features=None, language="en", tokens=toks, text=tk.decode(toks).strip(),
+                                avg_logprob=float(-rng.rand() * 1.5), no_speech_prob=float(rng.rand()),
+                                temperature=0.0, compression_ratio=1.0)
+
+    for trial in range(60):
+        seconds = float(rng.choice([7.0, 30.0, 47.3, 95.0]))
+        audio = torch.zeros(int(seconds * 16000))
+        results = [random_result() for _ in range(40)]
+        cond = bool(rng.randint(2))
+        thresholds = dict(no_speech_threshold=[None, 0.6][rng.randint(2)], logprob_threshold=[None, -1.0][rng.randint(2)])
+        used = []
+
+        def decode(segment, options, _r=results, _u=used):
+            _u.append(list(options.prompt or []))
+            return _r[len(_u) - 1]
+        model = types.SimpleNamespace(dims=types.SimpleNamespace(n_mels=80, n_audio_ctx=1500), is_multilingual=True, num_languages=99,
+                                      device=torch.device("cpu"), decode=decode)
+        want = W.transcribe(model, audio, temperature=0.0, condition_on_previous_text=cond, language="en", fp16=False,
+                            compression_ratio_threshold=None, **thresholds)
+        # the restatement, fed the same results in the same order
+        mel = W.log_mel_spectrogram(audio, 80, padding=480000)
+        st = streams._Stream(0, mel, mel.shape[-1] - 3000, None, tk, "en", [])
+        opts = dict(condition_on_previous_text=cond, **thresholds)
+        prompts, k = [], 0
+        while st.active():
+            st.window_mel()
+            prompts.append(st.all_tokens[st.prompt_reset_since:])
+            r = results[k]
+            k += 1
+            st.take_result(list(r.tokens), r.avg_logprob, r.no_speech_prob, 0.0, opts, W)
+        got = st.transcription()
+        assert k == len(used) and prompts == used, trial
+        assert got["text"] == want["text"] and len(got["segments"]) == len(want["segments"]), trial
+        for a, b in zip(got["segments"], want["segments"]):
+            a = dict(a, compression_ratio=b["compression_ratio"])              # (computed from the text on both sides)
+            assert a == b, (trial, a, b)
