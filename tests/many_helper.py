@@ -32,6 +32,21 @@ def script_clip(index):
     set_script(Script([G.window_script(50364, 50257, segs, "eot")]))
 
 
+def script_batch(indices):
+    """transcribe_many(streams=N): the scripted transcript for every recording of the worker's batch (one window each)."""
+    from whisper_double.decoding import Script, set_row_scripts
+    from golden import make_golden_transcribe as G
+    from whisper_timestamped import streams
+    window = G.window_script(50364, 50257, [(s, [None] * n, e) for s, n, e in SEGMENTS], "eot")
+    scripts = [Script([window]) for _ in indices]
+
+    def on_group(rows):
+        for r in rows:
+            scripts[r].begin_window()
+        set_row_scripts([scripts[r] for r in rows])
+    streams.ON_GROUP_DECODE = on_group
+
+
 class _Patch:
     """the two methods of pytest's monkeypatch that cpu_kernel_standin.install uses (a worker process has no fixture)"""
 

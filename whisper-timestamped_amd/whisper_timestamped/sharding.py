@@ -263,7 +263,8 @@ def transcribe_recordings(model, audios, dist=None, broadcast_weights: bool = Fa
 # with its own copy of the model (whisper-base: 290 MB of 288 GB) and its own HIP queues, fill the GPU the way W batch
 # streams would, with no change to the backend's loop and therefore to its output.  No collective anywhere: a job queue
 # in, result dictionaries out.
-def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options, barrier, out_queue, on_item, warmup):
+def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options, barrier, out_queue, on_item, warmup,
+                 streams=0, on_batch=None):
     """`mine` = the indices (into the caller's list) of this worker's recordings, `my_audios` = those recordings only."""
     import time
     import os
@@ -275,9 +276,13 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
     on_gpu = torch.device(dev).type == "cuda"      # (the CPU only ever appears in the host-logic tests)
     if on_gpu:
         torch.cuda.set_device(dev)
-    from .transcribe import transcribe_timestamped
+    from .transcribe import transcribe_batch, transcribe_timestamped
     model = load_model(dev)
-    if warmup and mine:                          # allocations, GEMM plans, the library's arenas: before the common start
+    if warmup and mine and streams and streams > 1:
+        if on_batch is not None:
+            on_batch(mine)
+        transcribe_batch(model, my_audios, max_streams=streams, **options)
+    elif warmup and mine:                        # allocations, GEMM plans, the library's arenas: before the common start
         if on_item is not None:
             on_item(mine[0])
         transcribe_timestamped(model, my_audios[0], **options)
@@ -287,22 +292,30 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
         barrier.wait(timeout=600)                # (BrokenBarrierError when the parent aborted it: a sibling died)
     t0 = time.perf_counter()
     res = []
-    for i, audio in zip(mine, my_audios):
-        if on_item is not None:
-            on_item(i)
-        res.append((i, transcribe_timestamped(model, audio, **options)))
+    if streams and streams > 1:                  # the worker's recordings as decoder streams (streams.py)
+        if on_batch is not None:
+            on_batch(mine)
+        res = list(zip(mine, transcribe_batch(model, my_audios, max_streams=streams, **options)))
+    else:
+        for i, audio in zip(mine, my_audios):
+            if on_item is not None:
+                on_item(i)
+            res.append((i, transcribe_timestamped(model, audio, **options)))
     if on_gpu:
         torch.cuda.synchronize(dev)
     out_queue.put((rank, time.perf_counter() - t0, res))
 
 
 def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, on_item=None, warmup: bool = False,
-                    return_timing: bool = False, **options):
+                    return_timing: bool = False, streams: int = 0, on_batch=None, **options):
     """transcribe_timestamped() of every recording in `audios` (1-D fp32 tensors / arrays at 16 kHz, or paths) on
     `workers_per_gpu` worker processes per GPU.  `load_model(device)` -> the model; it runs inside each worker and must
     be picklable (a module-level function), as must `on_item(index)` (called in the worker before item `index`).
     Recordings are dealt to the workers largest-first by length.  Returns the result dictionaries in the order of
-    `audios` (with `return_timing`: also the slowest worker's seconds between the common start and its last result)."""
+    `audios` (with `return_timing`: also the slowest worker's seconds between the common start and its last result).
+    `streams` > 1: every worker steps ITS recordings through the decoder together (transcribe_batch), so processes and
+    decoder streams multiply -- a B-stream decoder loop is bound by its one Python thread, W processes run W of them;
+    `on_batch(indices)` (picklable) is then called in the worker with its recordings' indices, in stream order."""
     import queue as queue_mod
     import torch.multiprocessing as mp
     from .naive import get_audio_tensor
@@ -316,7 +329,8 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     queue = ctx.Queue()
     # every worker is sent ITS recordings only (spawn pickles the arguments: W x the whole list otherwise)
     procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, [audios[i] for i in order[r]], order[r],
-                                                    options, barrier, queue, on_item, warmup)) for r in range(n_workers)]
+                                                    options, barrier, queue, on_item, warmup, streams, on_batch))
+             for r in range(n_workers)]
     for p in procs:
         p.daemon = True           # (a worker never outlives the process that asked for it)
         p.start()
