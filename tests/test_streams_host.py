@@ -260,3 +260,72 @@ def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
         for a, b in zip(got["segments"], want["segments"]):
             a = dict(a, compression_ratio=b["compression_ratio"])              # (computed from the text on both sides)
             assert a == b, (trial, a, b)
+
+
+@pytest.mark.parametrize("seed", [2024, 7])
+def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed):
+    """Beyond the goldens: recordings with RANDOM scripted transcripts -- one to three windows, segments of random sizes,
+    every ending the decoder can produce (closing timestamp, timestamp pair, no closing timestamp, token budget hit) --
+    through transcribe_batch (three ring blocks for eight recordings: continuous admission, ragged rounds, groups by
+    prompt length) and through transcribe() one at a time: identical dictionaries (oracle kernels on both sides)."""
+    import numpy as np
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams, words
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    monkeypatch.setattr(words, "RAW_CONFIDENCE", True)     # (before the reference's round(, 3): a rounding flip is not a difference)
+    rng = np.random.RandomState(seed)
+    ML, EOT = 50364, 50257
+    model = W.build_model("tiny", seed=0, device="cpu")
+
+    def random_window(last):
+        segs, t = [], int(rng.randint(0, 50))              # (the first timestamp of a window is at most 1.0 s: the filters)
+        for _ in range(rng.randint(1, 5)):
+            e = min(t + int(rng.randint(40, 420)), 1480)
+            n = int(rng.randint(1, 9))
+            segs.append((t, G.text_ids(int(rng.randint(1000)), n) if rng.rand() < 0.5 else [None] * n, e))
+            t = min(e + int(rng.randint(0, 25)), 1490)
+            if t >= 1480:
+                break
+        ending = ["eot", "pair", "noend", "eot"][rng.randint(4)] if last else ["eot", "pair"][rng.randint(2)]
+        return G.window_script(ML, EOT, segs, ending)
+
+    recs = []
+    for k in range(8):
+        n_win = int(rng.randint(1, 4))
+        seconds = 30.0 * (n_win - 1) + float(rng.uniform(6.0, 29.0))
+        g = torch.Generator().manual_seed(500 + k)
+        audio = (0.05 * torch.randn(int(seconds * 16000), generator=g)).float()
+        recs.append((audio, [random_window(j == n_win - 1) for j in range(n_win + 2)]))     # (+ spare windows, should the seek not reach the end)
+    opts = dict(language="en", fp16=False)
+    singles, recorded = [], []
+    for audio, windows in recs:
+        sc = set_script(Script(windows))
+        try:
+            singles.append(wt.transcribe(model, audio, **opts))
+        finally:
+            set_script(None)
+        recorded.append(sc.record)
+    scripts = [Script(r) for r in recorded]                 # replay exactly what each one-stream run sampled
+
+    def on_group(idx):
+        for i in idx:
+            scripts[i].begin_window()
+        set_row_scripts([scripts[i] for i in idx])
+    streams.ON_GROUP_DECODE = on_group
+    try:
+        batch = wt.transcribe_batch(model, [a for a, _ in recs], max_streams=3, **opts)
+    finally:
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    assert streams.LAST_RUN["ring_blocks"] == 3 and streams.LAST_RUN["admissions"] >= 3
+    n_words = 0
+    for b, s_, sc, rec in zip(batch, singles, scripts, recorded):
+        assert sc.record == rec
+        vb, vs = (json.loads(json.dumps(G.public_view(x), default=float)) for x in (b, s_))
+        compare(vb, vs, time_tol=0.0, conf_tol=2e-5, logprob_tol=1e-5)      # (GEMM batch-size rounding of the log-probs)
+        n_words += sum(len(x["words"]) for x in vb["segments"])
+    assert n_words > 40
