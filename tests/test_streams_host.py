@@ -262,8 +262,9 @@ def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
             assert a == b, (trial, a, b)
 
 
-@pytest.mark.parametrize("seed", [2024, 7])
-def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed):
+@pytest.mark.parametrize("seed,extra_opts", [(2024, None), (7, {"trust_whisper_timestamps": False}), (11, {"detect_disfluencies": True})],
+                         ids=["defaults", "no_trust", "disfluencies"])
+def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, extra_opts):
     """Beyond the goldens: recordings with RANDOM scripted transcripts -- one to three windows, segments of random sizes,
     every ending the decoder can produce (closing timestamp, timestamp pair, no closing timestamp, token budget hit) --
     through transcribe_batch (three ring blocks for eight recordings: continuous admission, ragged rounds, groups by
@@ -300,7 +301,7 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed):
         g = torch.Generator().manual_seed(500 + k)
         audio = (0.05 * torch.randn(int(seconds * 16000), generator=g)).float()
         recs.append((audio, [random_window(j == n_win - 1) for j in range(n_win + 2)]))     # (+ spare windows, should the seek not reach the end)
-    opts = dict(language="en", fp16=False)
+    opts = dict(language="en", fp16=False, **(extra_opts or {}))
     singles, recorded = [], []
     for audio, windows in recs:
         sc = set_script(Script(windows))
