@@ -48,6 +48,16 @@ def test_a_batch_of_eight_equals_eight_single_calls():
         compare(b, s, time_tol=0.0, conf_tol=2e-5, logprob_tol=1e-4)
 
 
+@pytest.mark.parametrize("seed,extra_opts", [(2024, None), (31, {"trust_whisper_timestamps": False}), (32, {"condition_on_previous_text": False})],
+                         ids=["defaults", "no_trust", "no_condition"])
+def test_random_scripts_streams_equal_one_stream_at_a_time_on_the_gpu(monkeypatch, seed, extra_opts):
+    """The random-script comparison of tests/test_streams_host.py with the real kernels: eight recordings of one to three
+    windows through three ring blocks (continuous admission: blocks are handed on while other streams go on) against
+    transcribe() one at a time -- same words, same times."""
+    from test_streams_host import test_random_scripts_streams_equal_one_stream_at_a_time as run
+    run(monkeypatch, seed, extra_opts, device="cuda:0", time_tol=0.0)
+
+
 def test_half_precision_model_streams_stay_close():
     """fp16=True (the reference's GPU default): the batch against its own one-stream run, same precision."""
     import whisper_double as W
