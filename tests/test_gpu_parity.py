@@ -598,6 +598,68 @@ def test_qk_rows_batch_vs_torch_and_single_window():
     assert torch.equal(ring16, ring32.half())
 
 
+def test_qk_rows_streams_writes_each_streams_block_and_nothing_else():
+    """wt_qk_rows_streams (B decoder streams, ONE launch per decoded token): batch entry b writes the LAST query row of every
+    selected head into ring block ring_index[b] at the given row -- the streams of a call being any subset of the blocks,
+    in any order; == (q * s) @ (k * s)^T in fp32 torch, == the single-stream entry; every other row of every block
+    untouched.  fp32 and fp16 projections, fp32 ring."""
+    import whisper_double as W
+    from whisper_timestamped import streams
+    W.install()
+    model = W.build_model("tiny", seed=0, device=DEV)
+    del model.alignment_heads                                    # -> the published tiny heads (parameter-count table)
+    from whisper_timestamped.transcribe import get_alignment_heads
+    heads = get_alignment_heads(model)
+    hooked = list(range(len(model.decoder.blocks)))
+    n_blocks, g = 6, torch.Generator().manual_seed(21)
+    rings = streams.StreamRings(model, heads, hooked, n_blocks, torch.float32)
+    D, H, hd, n_ctx = model.dims.n_text_state, model.dims.n_text_head, 64, 1500
+    sl, sh, ss = (t.tolist() for t in rings.sel)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.float16, 2e-2)):
+        rings.qk.fill_(-55.0)
+        idx = [4, 0, 3]                                          # three of the six blocks take part in this call
+        n_q = 5
+        qs = [None if l not in rings.used else (torch.randn((len(idx), n_q, D), generator=g) * 0.7).to(dtype).to(DEV)
+              for l in range(len(hooked))]
+        ks = [None if l not in rings.used else (torch.randn((len(idx), n_ctx, D), generator=g) * 0.7).to(dtype).to(DEV)
+              for l in range(len(hooked))]
+        rings.write_qk(qs, ks, torch.tensor(idx, dtype=torch.int32, device=DEV), row=9)
+        torch.cuda.synchronize()
+        scale = hd ** -0.25
+        for b, block in enumerate(idx):
+            for i, h, slot in zip(sl, sh, ss):
+                l = rings.used[i]
+                want = (qs[l][b, -1].float() * scale)[h * hd:(h + 1) * hd] @ (ks[l][b].float() * scale)[:, h * hd:(h + 1) * hd].T
+                got = rings.qk[block, slot, 9]
+                assert (got - want).abs().max().item() <= tol, (dtype, block, slot)
+        touched = torch.zeros_like(rings.qk, dtype=torch.bool)
+        touched[idx, :, 9] = True
+        assert (rings.qk[~touched] == -55.0).all()               # other rows, other blocks: as they were
+    with pytest.raises(_lib().WtError, match="ring_index"):     # a null ring_index is refused before anything is launched
+        rc = _lib().load().wt_qk_rows_streams(0, 0, 1, 0, 1, 1, 0, 0, 1500, 384, 64, 0.35, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0)
+        _lib()._check(rc, "wt_qk_rows_streams")
+
+
+def test_release_stream_frees_that_streams_arenas():
+    """wt_release_stream: a side stream used for one call owns scratch arenas (the log-mel filterbank bands, per-unit words);
+    releasing it frees them (count > 0), releasing it again frees nothing, and the stream can be used again afterwards."""
+    L = _lib()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    pcm = torch.randn((2, 48000), generator=g, device=DEV) * 0.1
+    fb = O.mel_filters_ref(80)
+    side = torch.cuda.Stream(device=DEV)
+    with torch.cuda.stream(side):
+        mel0, _ = L.logmel(pcm, fb, None, n_frames=300)
+    side.synchronize()
+    assert L.release_stream(side) >= 1
+    assert L.release_stream(side) == 0
+    with torch.cuda.stream(side):
+        mel1, _ = L.logmel(pcm, fb, None, n_frames=300)
+    side.synchronize()
+    assert torch.equal(mel0, mel1)
+    L.release_stream(side)
+
+
 def test_cost_rejects_more_than_256_rows():
     L = _lib()
     descs = L.make_descs(1)
