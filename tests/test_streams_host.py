@@ -189,6 +189,20 @@ def test_batched_timestamp_rules_equal_the_backends_row_by_row(monkeypatch):
             assert torch.equal(a, b), (sample_begin, n)
 
 
+def test_batched_suppress_tokens_equal_the_backends():
+    import whisper_double as W
+    from whisper_timestamped import streams
+    W.install()
+    theirs = W.decoding.SuppressTokens([3, 17, 50257, 220, 11])
+    mine = streams.BatchedSuppressTokens(theirs.suppress_tokens)
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn((5, 51865), generator=g)
+    b = a.clone()
+    theirs.apply(a, None)
+    mine.apply(b, None)
+    assert torch.equal(a, b) and int(torch.isinf(b).sum()) == 5 * 5
+
+
 def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
     """streams._Stream.take_result restates what the backend's transcribe() loop does with the DecodingResult of a window
     (no-speech skip, segments at consecutive timestamps, seek, prompt bookkeeping).  The one-stream path runs the

@@ -258,11 +258,37 @@ class BatchedTimestampRules:
         logits[:, :ts0].masked_fill_(take_ts[:, None], -np.inf)
 
 
+class BatchedSuppressTokens:
+    """openai-whisper's SuppressTokens.apply is `logits[:, <python list>] = -inf`: the list becomes an index tensor (host ->
+    device) on every call -- 2.8 ms per decoder call at 256 streams.  Same columns, the index built once."""
+
+    def __init__(self, suppress_tokens):
+        self.suppress_tokens = list(suppress_tokens)
+        self._idx = None
+
+    def apply(self, logits, tokens):
+        if self._idx is None or self._idx.device != logits.device:
+            self._idx = torch.tensor(self.suppress_tokens, dtype=torch.long, device=logits.device)
+        logits.index_fill_(1, self._idx, -np.inf)
+
+
 def vectorize_filters(task):
     if VECTORIZED_TIMESTAMP_RULES:
-        task.logit_filters = [BatchedTimestampRules.like(f) if type(f).__name__ == "ApplyTimestampRules" else f
-                              for f in task.logit_filters]
+        task.logit_filters = [BatchedTimestampRules.like(f) if type(f).__name__ == "ApplyTimestampRules"
+                              else BatchedSuppressTokens(f.suppress_tokens) if type(f).__name__ == "SuppressTokens" and hasattr(f, "suppress_tokens")
+                              else f for f in task.logit_filters]
     return task
+
+
+class _RowAlreadyInTheRing:
+    """What a stream's session is handed as `outs` for a replayed decoder call other than the prompt call: it only ever
+    takes `outs[0, -1]` of it, to append a row that the driver has already written into the stream's block."""
+
+    def __getitem__(self, key):
+        return None
+
+
+_IN_RING = _RowAlreadyInTheRing()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -744,9 +770,8 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         ses = s.session
         assert rec.calls[0][i] == s.initial_tokens
         ses.hook_decoder_logits(None, None, rec.first_outs[i:i + 1])
-        view = rings.logits[s.block]
         for k in range(1, len(sampled[i])):
             ses.on_tokens(rec.calls[k][i])
-            ses.hook_decoder_logits(None, None, view[k:k + 1].unsqueeze(0))
+            ses.hook_decoder_logits(None, None, _IN_RING)
         out_tokens, avg_logprob = results[i]
         s.take_result(out_tokens, avg_logprob, float(no_speech[i]), temperature, opts, w)
