@@ -286,11 +286,13 @@ class AlignmentBatch:
             # A refused batch (WT_E_UNSUPPORTED ...) must not cost the pool a slot -- but an entry point may have queued
             # kernels on this slot's buffers before a LATER one refused (align ok, disfluency refused): the slot only
             # goes back once the stream has drained, so nobody else can be handed buffers that are still being written.
-            try:
-                torch.cuda.current_stream(dev).synchronize()
-            except Exception:      # (a dead device: drop the slot instead of pooling it)
-                raise
-            else:
+            drained = True
+            if dev.type == "cuda":
+                try:
+                    torch.cuda.current_stream(dev).synchronize()
+                except Exception:                  # noqa: BLE001 -- a dead device: the slot is dropped, not pooled
+                    drained = False
+            if drained:
                 ws.release(slot)
             raise
         return self
