@@ -224,6 +224,31 @@ class EfficientSession:
             if not sot:
                 self.window_tokens_nosot.append(cur[-1])
 
+    def text_run_is_plain(self, n):
+        """Replay (streams.py): may the next n decoder calls of this stream, all of them fed one TEXT token, be booked in one
+        go (`on_text_run`)?  Yes while the window stays clear of the decoding limit (T.py:878-881: no fallback token is
+        recorded) -- a text token never flushes a segment (T.py:445-468 needs two timestamps in a row)."""
+        if not (self.replay and self.has_started and self.reuse is True and self.window_inputs):
+            return False
+        after = len(self.window_tokens_nosot) + n
+        return after + 2 < self.max_sample_len and after + 1 + len(self.window_inputs[0]) <= self.n_ctx
+
+    def on_text_run(self, toks, row_in_ring):
+        """`for t in toks: on_tokens([t]); hook_decoder_logits(row already in the ring)` for a run that
+        `text_run_is_plain`: what those calls leave behind is bookkeeping, done here at once."""
+        self._commit_pending_logits()             # the call before the run
+        n = len(toks)
+        self.segment_tokens[-1].extend(toks)
+        self.open_rows.extend(range(self.row_next, self.row_next + n))
+        self.row_next += n
+        self.window_inputs.extend([t] for t in toks)
+        self.ctx_len += n
+        self.window_tokens_nosot.extend(toks)
+        self.sot_index = None
+        self.logits.n += n - 1                    # every call of the run but the last has been committed by its successor
+        self.last_chunk_token = None
+        self.pending_logits = (row_in_ring, False)
+
     def hook_cross_attention(self, index, layer, ins, outs):
         assert isinstance(outs, tuple) and len(outs) == 2, "whisper seems to be outdated, please update it"
         if not self.has_started:

@@ -770,8 +770,18 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         ses = s.session
         assert rec.calls[0][i] == s.initial_tokens
         ses.hook_decoder_logits(None, None, rec.first_outs[i:i + 1])
-        for k in range(1, len(sampled[i])):
-            ses.on_tokens(rec.calls[k][i])
+        mine = [rec.calls[k][i][0] for k in range(1, len(sampled[i]))]     # the one token fed at calls 1, 2, ...
+        ts0, k, n = ses.tokenizer.timestamp_begin, 0, len(mine)
+        while k < n:
+            e = k
+            while e < n and mine[e] < ts0:
+                e += 1
+            if e - k >= 2 and ses.text_run_is_plain(e - k):         # a run of text tokens: booked at once
+                ses.on_text_run(mine[k:e], _IN_RING)
+                k = e
+                continue
+            ses.on_tokens([mine[k]])
             ses.hook_decoder_logits(None, None, _IN_RING)
+            k += 1
         out_tokens, avg_logprob = results[i]
         s.take_result(out_tokens, avg_logprob, float(no_speech[i]), temperature, opts, w)
