@@ -345,3 +345,35 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
         compare(vb, vs, time_tol=time_tol, conf_tol=2e-5, logprob_tol=1e-4 if device != "cpu" else 1e-5)     # (GEMM batch-size rounding)
         n_words += sum(len(x["words"]) for x in vb["segments"])
     assert n_words > 40
+
+
+def test_degenerate_batches(monkeypatch):
+    """One ring block for several recordings (strictly one after the other through the B-stream driver), an EMPTY
+    recording and a very short one among real ones: every recording still gets the dictionary transcribe() gives it."""
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    # (a) max_streams = 1
+    cases = same_model_cases()[:3]
+    for raw, case in zip(run_batch(cases, max_streams=1), cases):
+        compare(rounded(raw), case["expected"], time_tol=0.0, conf_tol=0.0, logprob_tol=1e-5)
+    assert streams.LAST_RUN["ring_blocks"] == 1 and streams.LAST_RUN["admissions"] == 3
+    # (b) an empty recording and a 0.3 s one between two real ones (scripts: whatever the model says, greedy)
+    case = same_model_cases()[0]
+    model, audio, _ = G.build_case(case, device="cpu")
+    audios = [audio, torch.zeros(0), audio[:4800], audio]
+    singles = []
+    for a in audios:
+        set_script(None)
+        singles.append(wt.transcribe(model, a, language="en", fp16=False, sample_len=12))
+    streams.ON_GROUP_DECODE = None
+    set_row_scripts(None)
+    batch = wt.transcribe_batch(model, audios, max_streams=3, language="en", fp16=False, sample_len=12)
+    assert batch[1]["segments"] == [] and batch[1]["text"] == ""
+    for b, s_ in zip(batch, singles):
+        vb, vs = (json.loads(json.dumps(G.public_view(x), default=float)) for x in (b, s_))
+        compare(vb, vs, time_tol=0.0, conf_tol=1e-3 + 1e-9, logprob_tol=1e-4)
