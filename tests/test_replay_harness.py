@@ -40,7 +40,7 @@ def test_without_checkpoints_every_case_is_skipped_and_named(tmp_path):
     R = load_tool()
     args = R.argparse.Namespace(reference=str(tmp_path), download_root=str(tmp_path), device="cuda", long=True, dump=None)
     rep = R.replay(args)
-    assert rep["replayed"] == 0 and rep["failed"] == 0 and rep["skipped"] == len(rep["cases"]) == 11
+    assert rep["replayed"] == 0 and rep["failed"] == 0 and rep["skipped"] == len(rep["cases"]) == 13
     for c in rep["cases"]:
         assert c["status"] == "skipped" and any(n.startswith("checkpoint ") for n in c["needs"])
     assert R.main(["--reference", str(tmp_path), "--download_root", str(tmp_path)]) == 0
@@ -76,7 +76,7 @@ def test_mechanics_on_a_fabricated_reference_tree(tmp_path, monkeypatch):
     rep = R.replay(args)
     ran = [c for c in rep["cases"] if c["status"] != "skipped"]
     assert len(ran) == 1 and ran[0]["status"] == "ok" and ran[0]["max_abs_dt_word_s"] == 0 and ran[0]["within_baseline_bars"]
-    assert rep["replayed"] == 1 and rep["failed"] == 0 and rep["skipped"] == 8
+    assert rep["replayed"] == 1 and rep["failed"] == 0 and rep["skipped"] == 10
     moved = copy.deepcopy(first)
     moved["segments"][0]["words"][0]["start"] += 0.3
     with open(case["expected"], "w", encoding="utf-8") as f:

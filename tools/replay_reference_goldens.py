@@ -11,6 +11,8 @@ path:
                    on bonjour_vous_allez_bien.mp3                       (test_monolingual_tiny, :454-477)
   tiny_auto        transcribe(load_model("tiny"), f) for bonjour.wav, laugh1.mp3, laugh2.mp3   (test_python_import, :704-711)
   tiny_fr          the same with language="fr"                                                   (:713-717)
+  tiny_auto/batch  the three tiny_auto recordings through ONE transcribe_batch call (B decoder streams: not a reference
+  tiny_fr/batch    test, the same goldens), and the three tiny_fr ones
   naive            cli --model small --language en {--naive | --accurate} on apollo11.mp3 (long; only with --long)
 
 It needs what this image does not have: the openai-whisper package, the checkpoints (tiny.en.pt, tiny.pt, [small.pt]
@@ -105,6 +107,10 @@ def cases(args):
         for fn in ("bonjour.wav", "laugh1.mp3", "laugh2.mp3"):
             out.append(dict(name=f"{sub}/{fn}", kind="api", model="tiny", audio=os.path.join(data, fn), kwargs=kw,
                             expected=os.path.join(exp, sub, f"{fn}.words.json")))
+    for sub, kw in (("tiny_auto", {}), ("tiny_fr", {"language": "fr"})):
+        fns = ("bonjour.wav", "laugh1.mp3", "laugh2.mp3")
+        out.append(dict(name=f"{sub}/batch", kind="api_batch", model="tiny", audio=[os.path.join(data, fn) for fn in fns], kwargs=kw,
+                        expected=[os.path.join(exp, sub, f"{fn}.words.json") for fn in fns]))
     if args.long:
         clip = os.path.join(data, "apollo11.mp3")
         for prefix, opts in (("naive", ["--naive"]), ("accurate", ["--accurate"])):   # (reference: test_naive, :332-346)
@@ -116,9 +122,11 @@ def cases(args):
 
 def missing_for(case, have):
     miss = [k for k in ("openai-whisper", "gpu", "libwtalign.so", f"checkpoint {case['model']}") if not have.get(k)]
-    if not case["audio"].endswith(".wav") and not have["ffmpeg"]:
+    audios = case["audio"] if isinstance(case["audio"], list) else [case["audio"]]
+    expected = case["expected"] if isinstance(case["expected"], list) else [case["expected"]]
+    if any(not a.endswith(".wav") for a in audios) and not have["ffmpeg"]:
         miss.append("ffmpeg")
-    for path in (case["audio"], case["expected"]):
+    for path in audios + expected:
         if not os.path.isfile(path):
             miss.append(path)
     return miss
@@ -126,6 +134,11 @@ def missing_for(case, have):
 
 def run_case(case, args, models):
     import whisper_timestamped as wt
+    if case["kind"] == "api_batch":
+        if case["model"] not in models:
+            models[case["model"]] = wt.load_model(case["model"], device=args.device, download_root=args.download_root)
+        res = wt.transcribe_batch(models[case["model"]], case["audio"], **case["kwargs"])
+        return [json.loads(json.dumps(r, ensure_ascii=False, default=float)) for r in res]
     if case["kind"] == "api":
         if case["model"] not in models:
             models[case["model"]] = wt.load_model(case["model"], device=args.device, download_root=args.download_root)
@@ -153,10 +166,21 @@ def replay(args):
             rec.update(status="skipped", needs=miss)
             report["skipped"] += 1
         else:
-            got = norm_language(run_case(case, args, models))
-            want = norm_language(json.load(open(case["expected"], encoding="utf-8")))
-            same = loose(got) == loose(want)
-            dt, dc, comparable = word_gaps(got, want)
+            got = run_case(case, args, models)
+            if case["kind"] == "api_batch":              # several recordings, one call: every one against its own golden
+                wants = [norm_language(json.load(open(e, encoding="utf-8"))) for e in case["expected"]]
+                gots = [norm_language(g) for g in got]
+                same = all(loose(g) == loose(w_) for g, w_ in zip(gots, wants)) and len(gots) == len(wants)
+                gaps = [word_gaps(g, w_) for g, w_ in zip(gots, wants)]
+                comparable = all(g[2] for g in gaps)
+                dt = max((g[0] for g in gaps), default=0.0) if comparable else None
+                dc = max((g[1] for g in gaps), default=0.0) if comparable else None
+                got, want = {"recordings": gots}, {"recordings": wants}
+            else:
+                got = norm_language(got)
+                want = norm_language(json.load(open(case["expected"], encoding="utf-8")))
+                same = loose(got) == loose(want)
+                dt, dc, comparable = word_gaps(got, want)
             rec.update(status="ok" if same else "DIFFERENT", reference_loose_comparison=same, same_words=comparable,
                        max_abs_dt_word_s=dt, max_abs_dconfidence=dc,
                        within_baseline_bars=bool(comparable and dt <= 0.02 + 1e-9 and dc <= 1e-3 + 1e-9))
