@@ -79,3 +79,31 @@ def test_cli_options_are_the_reference_ones():
         assert d[k] == v, (k, d[k], v)
     with pytest.raises(ValueError):
         C._output_formats("json,doc")
+
+
+def test_cli_streams_writes_the_same_files_as_one_after_the_other(tmp_path, monkeypatch):
+    """--streams N (not in the reference): several audio files through ONE transcribe_batch call; the output files must be
+    those of the default, one-file-after-the-other run."""
+    from test_streams_host import install_streams_standin
+    C = _patch(monkeypatch)
+    install_streams_standin(monkeypatch)
+    wavs = []
+    for k, seconds in enumerate((2.5, 4.0, 1.2)):
+        w = tmp_path / f"clip{k}.wav"
+        _wav(str(w), seconds=seconds, seed=k)
+        wavs.append(str(w))
+    common = ["--model", "tiny", "--device", "cpu", "--language", "en", "--fp16", "False", "--output_format", "json,srt", "--efficient"]
+    C.cli([*wavs, "--output_dir", str(tmp_path / "serial"), *common])
+    C.cli([*wavs, "--output_dir", str(tmp_path / "streams"), "--streams", "2", *common])
+    names = sorted(os.listdir(tmp_path / "serial"))
+    assert names == sorted(os.listdir(tmp_path / "streams")) and len(names) == 9
+    for n in names:
+        a, b = (tmp_path / "serial" / n).read_text(), (tmp_path / "streams" / n).read_text()
+        if n.endswith(".json"):
+            ja, jb = json.loads(a), json.loads(b)
+            assert ja["text"] == jb["text"] and len(ja["segments"]) == len(jb["segments"])
+            for sa, sb in zip(ja["segments"], jb["segments"]):
+                assert [(w["text"], w["start"], w["end"]) for w in sa["words"]] == [(w["text"], w["start"], w["end"]) for w in sb["words"]]
+                assert all(abs(x["confidence"] - y["confidence"]) <= 1e-3 + 1e-9 for x, y in zip(sa["words"], sb["words"]))
+        else:
+            assert a == b, n

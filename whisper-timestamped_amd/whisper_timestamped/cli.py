@@ -15,7 +15,7 @@ import torch
 
 from . import backend as _backend
 from .output import filtered_keys, flatten, remove_keys, write_csv
-from .transcribe import load_model, transcribe_timestamped
+from .transcribe import load_model, transcribe_batch, transcribe_timestamped
 
 logger = logging.getLogger("whisper_timestamped")
 VALID_FORMATS = ["txt", "vtt", "srt", "tsv", "csv", "json"]
@@ -116,6 +116,9 @@ def build_parser():
                    help="Shortcut to use the same default option as in openai-whisper (best_of=5, beam_search=5, temperature_increment_on_fallback=0.2)")
     p.add_argument("--efficient", action=shortcut(best_of=None, beam_size=None, temperature_increment_on_fallback=None),
                    help="Shortcut to disable beam size and options that requires to sample several times, for an efficient decoding")
+    p.add_argument("--streams", type=int, default=0,
+                   help="(not in the reference) with several audio files: step up to this many of them through the decoder "
+                        "together (transcribe_batch); 0 = one file after the other, as the reference does.  Same output files")
     p.add_argument("--naive", default=False, action="store_true",
                    help="use naive approach, doing inference twice (once to get the transcription, once to get word timestamps and confidence scores).")
     return p
@@ -148,11 +151,18 @@ def cli(argv=None):
     args["compute_word_confidence"] = args.pop("compute_confidence")
     args["trust_whisper_timestamps"] = not args.pop("recompute_all_timestamps")
     write = _writers()
+    n_streams = args.pop("streams")
+    results = None
+    if n_streams and n_streams > 1 and len(audio_files) > 1 and not plot:
+        # independent recordings: up to n_streams of them per decoder op (calls the B-stream path cannot take -- beam
+        # search, temperature fallback, vad -- are decoded one after the other by transcribe_batch itself)
+        results = transcribe_batch(model, audio_files, max_streams=n_streams, temperature=temperature, **args)
 
-    for audio_path in audio_files:
+    for k, audio_path in enumerate(audio_files):
         outname = os.path.join(output_dir, os.path.basename(audio_path)) if output_dir else None
-        result = transcribe_timestamped(model, audio_path, temperature=temperature,
-                                        plot_word_alignment=outname if (outname and plot) else plot, **args)
+        result = results[k] if results is not None else \
+            transcribe_timestamped(model, audio_path, temperature=temperature,
+                                   plot_word_alignment=outname if (outname and plot) else plot, **args)
         if not output_dir:
             if not args["verbose"]:
                 json.dump(filtered_keys(result), sys.stdout, indent=2, ensure_ascii=False)
