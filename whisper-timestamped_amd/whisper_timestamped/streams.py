@@ -523,6 +523,18 @@ def backend_missing():
     return missing
 
 
+def _length_hint(audio):
+    """Samples of a recording given as an array / tensor; for a path, its file size (files of one codec scale with their
+    duration: good enough to order them)."""
+    if isinstance(audio, str):
+        import os
+        try:
+            return os.path.getsize(audio)
+        except OSError:
+            return 0
+    return int(audio.shape[-1]) if hasattr(audio, "shape") and len(audio.shape) else 0
+
+
 def _whole_file_mels(model, audios, dtype):
     """Every recording's log-mel over the whole file + 30 s of silence, file-global max clamp (whisper's transcribe():
     log_mel_spectrogram(audio, n_mels, padding=N_SAMPLES)) on the GPU; recordings of equal length share a launch."""
@@ -596,7 +608,9 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     sink = _Sink(default_workspace(dev))
     streams = [None] * N                                  # by recording
     free = list(range(S))
-    pending = list(range(N))
+    # longest recordings first (as sharding.partition_units deals units to ranks): a long recording admitted last would
+    # decode alone at the end.  Results go back in the caller's order whatever the order of admission.
+    pending = sorted(range(N), key=lambda i: (-_length_hint(audios[i]), i)) if N > S else list(range(N))
     admissions = 0
 
     def admit():
