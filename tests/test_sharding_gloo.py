@@ -219,6 +219,7 @@ def _islands_worker(rank, world, port, out_path, streams=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(4)                        # (two ranks share the host's cores)
     patch = pytest.MonkeyPatch()
     try:
         job = _islands_job()
