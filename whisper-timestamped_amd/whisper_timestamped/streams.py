@@ -665,63 +665,68 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     rounds = groups = 0
     verify = efficient.REUSE_DECODER_LOGITS == "auto"
     fused_checked = False
-    with torch.no_grad():
-        while True:
-            admit()
-            for st in streams:                            # (recordings with nothing to decode: empty audio)
-                if st is not None and not st.done and not st.active():
-                    retire(st)
-            act = [st for st in streams if st is not None and st.active()]
-            if not act:
-                if pending:
-                    continue
-                break
-            rounds += 1
-            # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
-            mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
-            pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
-            for j, st in enumerate(act):
-                kwargs = {k: opts[k] for k in decode_keys if k in opts}
-                kwargs["language"] = st.language
-                kwargs["prompt"] = st.all_tokens[st.prompt_reset_since:]
-                if temperature > 0:
-                    kwargs.pop("beam_size", None), kwargs.pop("patience", None)
-                else:
-                    kwargs.pop("best_of", None)
-                st.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
-                st.initial_tokens = list(st.task.initial_tokens)
-                st.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
-                st.session.on_tokens(list(st.initial_tokens))
-            sink.launch()
-            # ---- one batched decoder loop per initial-token length
-            by_len = {}
-            for j, st in enumerate(act):
-                by_len.setdefault(len(st.initial_tokens), []).append(j)
-            for L, members in by_len.items():
-                groups += 1
-                grp = [act[j] for j in members]
-                if ON_GROUP_DECODE is not None:
-                    ON_GROUP_DECODE([st.index for st in grp])
-                task = vectorize_filters(grp[0].task)
-                ring_index = torch.tensor([st.block for st in grp], dtype=torch.int32, device=dev)
-                rec = _Recorder(model, rings, hooked_blocks, ring_index, verify=verify)
-                rec.fused_checked = fused_checked or not efficient.FUSED_ATTENTION
-                task.decoder.reset()
-                rec.install()
-                try:
-                    feats = task._get_audio_features(mel_batch[members])
-                    tokens0 = torch.tensor([st.initial_tokens for st in grp], device=dev)
-                    tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
-                    rec.commit()
-                finally:
-                    rec.remove()
-                fused_checked = True
-                _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify)
-            for st in act:                                # finished recordings hand their blocks to the next ones
-                if not st.active():
-                    retire(st)
-        sink.resolve()
-        out = [st.session.compiled(st.transcription()) for st in streams]
+    try:
+        with torch.no_grad():
+            while True:
+                admit()
+                for st in streams:                            # (recordings with nothing to decode: empty audio)
+                    if st is not None and not st.done and not st.active():
+                        retire(st)
+                act = [st for st in streams if st is not None and st.active()]
+                if not act:
+                    if pending:
+                        continue
+                    break
+                rounds += 1
+                # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
+                mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
+                pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
+                for j, st in enumerate(act):
+                    kwargs = {k: opts[k] for k in decode_keys if k in opts}
+                    kwargs["language"] = st.language
+                    kwargs["prompt"] = st.all_tokens[st.prompt_reset_since:]
+                    if temperature > 0:
+                        kwargs.pop("beam_size", None), kwargs.pop("patience", None)
+                    else:
+                        kwargs.pop("best_of", None)
+                    st.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
+                    st.initial_tokens = list(st.task.initial_tokens)
+                    st.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
+                    st.session.on_tokens(list(st.initial_tokens))
+                sink.launch()
+                # ---- one batched decoder loop per initial-token length
+                by_len = {}
+                for j, st in enumerate(act):
+                    by_len.setdefault(len(st.initial_tokens), []).append(j)
+                for L, members in by_len.items():
+                    groups += 1
+                    grp = [act[j] for j in members]
+                    if ON_GROUP_DECODE is not None:
+                        ON_GROUP_DECODE([st.index for st in grp])
+                    task = vectorize_filters(grp[0].task)
+                    ring_index = torch.tensor([st.block for st in grp], dtype=torch.int32, device=dev)
+                    rec = _Recorder(model, rings, hooked_blocks, ring_index, verify=verify)
+                    rec.fused_checked = fused_checked or not efficient.FUSED_ATTENTION
+                    task.decoder.reset()
+                    rec.install()
+                    try:
+                        feats = task._get_audio_features(mel_batch[members])
+                        tokens0 = torch.tensor([st.initial_tokens for st in grp], device=dev)
+                        tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
+                        rec.commit()
+                    finally:
+                        rec.remove()
+                    fused_checked = True
+                    _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify)
+                for st in act:                                # finished recordings hand their blocks to the next ones
+                    if not st.active():
+                        retire(st)
+            sink.resolve()
+            out = [st.session.compiled(st.transcription()) for st in streams]
+    finally:
+        for batch, _ in sink.in_flight:           # (an error mid-run: the launched batches hand their buffers back)
+            batch.release()
+        sink.in_flight = []
     LAST_RUN.clear()
     LAST_RUN.update(streams=N, ring_blocks=S, admissions=admissions, rounds=rounds, decoder_loops=groups,
                     alignment_launch_sets=sink.launch_sets)
