@@ -200,3 +200,13 @@ def test_against_openai_whisper_where_installed():
             assert ours.decode(ids) == theirs.decode(ids)
             assert ours.decode_with_timestamps([ours.timestamp_begin + 7] + ids) == \
                 theirs.decode_with_timestamps([theirs.timestamp_begin + 7] + ids)
+
+
+def test_language_table_equals_transformers():
+    """The ORDER of the language list decides every language token id.  Independent source: the table transformers ships
+    for its own Whisper tokenizer (same 100 languages, same order, same aliases)."""
+    hf = pytest.importorskip("transformers.models.whisper.tokenization_whisper")
+    assert list(hf.LANGUAGES.items()) == list(TK.LANGUAGES.items())
+    assert hf.TO_LANGUAGE_CODE == TK.TO_LANGUAGE_CODE
+    names = TK.special_token_names(100)
+    assert names[2] == "<|en|>" and names[101] == "<|yue|>" and names[102] == "<|translate|>" and len(names) == 2 + 100 + 6 + 1501
