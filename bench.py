@@ -1392,6 +1392,12 @@ def orchestrate(args):
                 small["fp16_legs_error"] = e5
             e2e["whisper_small_shapes"] = small
             out["e2e"] = e2e
+            # the second half of BASELINE.json's metric ("...; max |dt_word| vs ref"), from the legs that compare words with
+            # the reference-shaped CPU path: the teacher-forced second pass and the default strategy
+            dts = [e2e.get("parity_vs_cpu_reference_path", {}).get("max_abs_dt_word_s"),
+                   eff.get("parity_vs_cpu_reference_path", {}).get("max_abs_dt_word_s")]
+            dts = [x for x in dts if x is not None]
+            out["max_abs_dt_word_vs_ref_s"] = max(dts) if dts else None
     print(json.dumps(out), flush=True)
     if out.get("value") is None:
         sys.exit(1)
