@@ -1394,10 +1394,13 @@ def orchestrate(args):
             out["e2e"] = e2e
             # the second half of BASELINE.json's metric ("...; max |dt_word| vs ref"), from the legs that compare words with
             # the reference-shaped CPU path: the teacher-forced second pass and the default strategy
-            dts = [e2e.get("parity_vs_cpu_reference_path", {}).get("max_abs_dt_word_s"),
-                   eff.get("parity_vs_cpu_reference_path", {}).get("max_abs_dt_word_s")]
-            dts = [x for x in dts if x is not None]
-            out["max_abs_dt_word_vs_ref_s"] = max(dts) if dts else None
+            try:
+                dts = [(e2e.get("parity_vs_cpu_reference_path") or {}).get("max_abs_dt_word_s"),
+                       (eff.get("parity_vs_cpu_reference_path") or {}).get("max_abs_dt_word_s")]
+                dts = [float(x) for x in dts if x is not None]
+                out["max_abs_dt_word_vs_ref_s"] = max(dts) if dts else None
+            except Exception:                              # noqa: BLE001 -- a summary key must never cost the line
+                out["max_abs_dt_word_vs_ref_s"] = None
     print(json.dumps(out), flush=True)
     if out.get("value") is None:
         sys.exit(1)
