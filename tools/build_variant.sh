@@ -6,7 +6,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; W=/tmp/wt_variant_$name; rm -rf $W; mkdir -p $W/pkg/csrc $W/include $R/tools/variants
 cp $R/include/*.h $W/include/
-cp $R/whisper-timestamped_amd/csrc/*.hip $R/whisper-timestamped_amd/csrc/*.h $R/whisper-timestamped_amd/csrc/Makefile $W/pkg/csrc/
+cp $R/whisper-timestamped_amd/csrc/*.hip $R/whisper-timestamped_amd/csrc/*.h $R/whisper-timestamped_amd/csrc/Makefile $R/whisper-timestamped_amd/csrc/wtalign.map $W/pkg/csrc/
 [ -n "$2" ] && sed -i -E "$2" $W/pkg/csrc/wt_dtw.hip
 [ -n "$3" ] && sed -i -E "$3" $W/pkg/csrc/wt_cost.hip
 [ -n "$4" ] && sed -i -E "$4" $W/pkg/csrc/wt_logmel.hip
