@@ -31,9 +31,9 @@
 extern "C" {
 #endif
 
-#define WT_ABI_VERSION 4 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3;
+#define WT_ABI_VERSION 5 /* 2: + wt_qk_rows_batch, wt_logprob_gather_rows, wt_dtw_batch_pattern; 3: + wt_align_batch_v3;
                             4: + wt_release_stream, wt_qk_rows_streams, wt_logmel_pad_batch; only the WT_API entries are exported (the library is built with
-                               -fvisibility=hidden) */
+                               -fvisibility=hidden); 5: + wt_logprob_digest_streams */
 
 /* The exported surface: exactly the functions marked WT_API below (tests/test_host_cpu.py holds `nm -D` to it). */
 #define WT_API __attribute__((visibility("default")))
@@ -230,6 +230,28 @@ WT_API int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t
  * windows at once, read from one padded (n_windows * T_max, V) logits block (no logit filters on this path, T.py:1245). */
 WT_API int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_stride, const int32_t *row_index, int n_out,
                            int V, const int32_t *token, float *out, void *stream);
+
+/* The confidence path for B decoder STREAMS stepping together (T.py:849-881 with B recordings in one decoder call
+ * instead of the reference's batch of one, T.py:806).  The reference keeps every step's filtered (V,) logits vector
+ * (T.py:875-876) until the window closes; here, when a decoder call's rows are final (the sampler has filtered them in
+ * place, the sampled tokens are known), ONE launch takes from each row everything the hook state machine can still
+ * ask of it, and the row itself is not kept:
+ *   digest[blk][ring_row][0]    log_softmax(row)[token]      (T.py:735; bit-identical to wt_logprob_gather_batch)
+ *   digest[blk][ring_row][1..2] max(row), log(sum(exp(row - max))):  log_softmax(row)[t] = (row[t] - [1]) - [2]
+ *   digest[blk][ring_row][3]    argmax(row) as int32 bits, first index of the maximum   (T.py:508,729,879)
+ *   digest[blk][ring_row][4..7] row[aux_tokens[k]] (raw logits; -inf for k >= n_aux): <|endoftext|>, <|notimestamps|> ...
+ *   slice[blk][ring_row][:]     row[slice_begin:V] (raw logits): the timestamp tokens -- T.py:535 takes
+ *                               argmax(row[start_token + 1:]) with start_token a timestamp; optional (NULL = none)
+ * with blk = ring_index[r] for batch row r.
+ *   logits     : device fp32, row r at logits + r*row_stride (the (n_rows, n_q, V) decoder output's last position)
+ *   token      : device int32 (token_dtype 0) or int64 (1), row r's token at token[r*token_stride]
+ *   ring_index : device int32[n_rows]; digest: device fp32 [n_blocks][ring_rows][8]; slice: device fp32
+ *                [n_blocks][ring_rows][V - slice_begin]
+ *   aux_tokens_host : HOST int32[n_aux], n_aux <= 4 */
+WT_API int wt_logprob_digest_streams(const float *logits, int64_t row_stride, int n_rows, int V, const void *token, int token_dtype,
+                                     int64_t token_stride, const int32_t *ring_index, int64_t ring_rows, int64_t ring_row,
+                                     const int32_t *aux_tokens_host, int n_aux, int slice_begin, float *digest, float *slice,
+                                     void *stream);
 
 /* openai-whisper audio.log_mel_spectrogram + pad_or_trim as called at
  * T.py:1213-1214 (naive path; n_frames = 3000) for a batch of equal-length

@@ -97,3 +97,16 @@ def test_half_precision_model_streams_stay_close():
         # a path can move where two columns tie within that noise: most boundaries identical, none of them far away.
         close = sum(d <= 0.04 + 1e-9 for d in dts)
         assert close >= 0.85 * len(dts) and max(dts) <= 1.0, (close, len(dts), max(dts))
+
+
+@pytest.mark.gpu
+def test_logprob_digest_streams_kernel_against_the_full_rows():
+    """wt_logprob_digest_streams (the real kernel through the C ABI) under the same checks as the host test's stand-in,
+    and: record [0] is BIT-identical to wt_logprob_gather_batch on the same rows and tokens."""
+    from test_streams_host import check_logits_view
+    from whisper_timestamped import _lib
+    rings, full, sampled, host = check_logits_view("cuda:0")
+    n_steps, g, V = full.shape
+    for step in range(n_steps):
+        lp = _lib.logprob_gather(full[step].cuda(), sampled[step].to(torch.int32).cuda()).cpu().numpy()
+        assert (lp == host[:, step, 0]).all(), (step, lp, host[:, step, 0])

@@ -35,6 +35,24 @@ def install_streams_standin(monkeypatch):
             self.qk[ring_index.long(), s, row] = (q @ k.transpose(1, 2))[:, 0].float().to(self.qk.dtype)
     monkeypatch.setattr(streams.StreamRings, "write_qk", write_qk)
 
+    def write_digest(self, rows, tokens, ring_index, step):
+        """wt_logprob_digest_streams restated with torch CPU ops (include/wtalign.h): [0] log_softmax(row)[token],
+        [1] max, [2] log(sum(exp(row - max))), [3] argmax bits, [4..] raw logits of the aux tokens; the timestamp slice."""
+        import numpy as np
+        x = rows.float()
+        idx = ring_index.long()
+        m = x.max(dim=1).values
+        rec = torch.full((x.shape[0], 8), float("-inf"))
+        rec[:, 0] = torch.log_softmax(x, dim=-1)[torch.arange(x.shape[0]), tokens.long()]
+        rec[:, 1] = m
+        rec[:, 2] = torch.logsumexp(x, dim=1) - m
+        rec[:, 3] = torch.from_numpy(x.argmax(dim=1).to(torch.int32).numpy().view(np.float32).copy())
+        for k, t in enumerate(self.aux_tokens):
+            rec[:, 4 + k] = x[:, t]
+        self.digest[idx, step] = rec
+        self.slice[idx, step] = x[:, self.slice_begin:]
+    monkeypatch.setattr(streams.StreamRings, "write_digest", write_digest)
+
 
 def run_batch(cases, device="cpu", raw_confidence=True, max_streams=32, **extra):
     """transcribe_batch on the recordings of `cases` (same model, same options), every stream's sampler steered by its
@@ -278,7 +296,7 @@ def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
 
 @pytest.mark.parametrize("seed,extra_opts", [(2024, None), (7, {"trust_whisper_timestamps": False}), (11, {"detect_disfluencies": True})],
                          ids=["defaults", "no_trust", "disfluencies"])
-def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, extra_opts, device="cpu", time_tol=0.0):
+def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, extra_opts, device="cpu", time_tol=0.0, hold=0, n_wins=None):
     """Beyond the goldens: recordings with RANDOM scripted transcripts -- one to three windows, segments of random sizes,
     every ending the decoder can produce (closing timestamp, timestamp pair, no closing timestamp, token budget hit) --
     through transcribe_batch (three ring blocks for eight recordings: continuous admission, ragged rounds, groups by
@@ -293,6 +311,7 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
         cpu_kernel_standin.install(monkeypatch)
         install_streams_standin(monkeypatch)
     monkeypatch.setattr(words, "RAW_CONFIDENCE", True)     # (before the reference's round(, 3): a rounding flip is not a difference)
+    monkeypatch.setattr(streams, "HOLD_FOR_BUCKET", hold)
     rng = np.random.RandomState(seed)
     ML, EOT = 50364, 50257
     model = W.build_model("tiny", seed=0, device=device)
@@ -310,8 +329,8 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
         return G.window_script(ML, EOT, segs, ending)
 
     recs = []
-    for k in range(8):
-        n_win = int(rng.randint(1, 4))
+    for k in range(8 if n_wins is None else len(n_wins)):
+        n_win = int(rng.randint(1, 4)) if n_wins is None else n_wins[k]
         seconds = 30.0 * (n_win - 1) + float(rng.uniform(6.0, 29.0))
         g = torch.Generator().manual_seed(500 + k)
         audio = (0.05 * torch.randn(int(seconds * 16000), generator=g)).float()
@@ -337,14 +356,23 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
     finally:
         streams.ON_GROUP_DECODE = None
         set_row_scripts(None)
-    assert streams.LAST_RUN["ring_blocks"] == 3 and streams.LAST_RUN["admissions"] >= 3
+    assert streams.LAST_RUN["ring_blocks"] == 3 and (streams.LAST_RUN["admissions"] >= 3 or n_wins is not None)
+    assert sum(streams.LAST_RUN["streams_per_loop"]) >= len(recs) and len(streams.LAST_RUN["streams_per_loop"]) == streams.LAST_RUN["decoder_loops"]
+    assert (streams.LAST_RUN["windows_held_one_round"] > 0) == (hold > 1)
     n_words = 0
     for b, s_, sc, rec in zip(batch, singles, scripts, recorded):
         assert sc.record == rec
         vb, vs = (json.loads(json.dumps(G.public_view(x), default=float)) for x in (b, s_))
         compare(vb, vs, time_tol=time_tol, conf_tol=2e-5, logprob_tol=1e-4 if device != "cpu" else 1e-5)     # (GEMM batch-size rounding)
         n_words += sum(len(x["words"]) for x in vb["segments"])
-    assert n_words > 40
+    assert n_words > (40 if n_wins is None else 10)
+
+
+def test_bucket_admission_does_not_change_any_result(monkeypatch):
+    """HOLD_FOR_BUCKET: streams whose prompt length nobody shares sit a round out -- same dictionaries as one stream at a time."""
+    # three ring blocks; A has two windows, the others one: in round 2 A's second window (a prompt of its own length) meets
+    # the first windows of D and E (equal prompts) and sits that round out
+    test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, 2024, None, hold=2, n_wins=[2, 1, 1, 1, 1])
 
 
 def test_degenerate_batches(monkeypatch):
@@ -377,3 +405,116 @@ def test_degenerate_batches(monkeypatch):
     for b, s_ in zip(batch, singles):
         vb, vs = (json.loads(json.dumps(G.public_view(x), default=float)) for x in (b, s_))
         compare(vb, vs, time_tol=0.0, conf_tol=1e-3 + 1e-9, logprob_tol=1e-4)
+
+
+def check_logits_view(device, write_digest=None):
+    """_LogitsView over StreamRings' digests against the full rows it no longer keeps: the sampled token's log-probability,
+    the argmax, the log-probability of the argmax / <|endoftext|> / <|notimestamps|> / any timestamp token, the argmax over
+    later timestamps (T.py:535) -- and a loud refusal for anything else.  Shared by the CPU test (stand-in digest) and the
+    GPU test (wt_logprob_digest_streams)."""
+    import numpy as np
+    import whisper_double as W
+    from whisper_timestamped import _lib, streams
+    W.install()
+    model = W.build_model("tiny", seed=0, device=device)
+    tk = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    heads = torch.tensor([[2, 1], [3, 0], [3, 4]])
+    n_streams, g, n_steps = 5, 3, 7
+    rings = streams.StreamRings(model, heads, [0, 1, 2, 3], n_streams, torch.float32, sample_len=20, tokenizer=tk)
+    assert rings.capacity == 21 and rings.digest.shape == (n_streams, 21, 8)
+    V, ts0 = model.dims.n_vocab, tk.timestamp_begin
+    gen = torch.Generator().manual_seed(3)
+    blocks = [4, 0, 2]
+    ring_index = torch.tensor(blocks, dtype=torch.int32, device=device)
+    full = torch.randn((n_steps, g, V), generator=gen) * 3
+    full[:, :, tk.no_timestamps] = float("-inf")
+    full[2, 1, 700] = full[2, 1, 9000] = full[2, 1].max() + 1.0             # a tie: the FIRST index wins, as torch.argmax
+    sampled = torch.randint(0, V, (n_steps, g), generator=gen)
+    sampled[3, 0] = ts0 + 40
+    before = rings.digest.clone()
+    for step in range(n_steps):
+        # the prompt call's rows come out of a (g, n_q, V) tensor (row stride n_q * V); tokens as a strided int64 column
+        outs = torch.zeros((g, 3, V))
+        outs[:, -1] = full[step]
+        toks = torch.zeros((g, 4), dtype=torch.int64)
+        toks[:, -1] = sampled[step]
+        rings.write_digest(outs.to(device)[:, -1], toks.to(device)[:, -1], ring_index, step)
+    untouched = [b for b in range(n_streams) if b not in blocks]
+    assert torch.equal(rings.digest[untouched], before[untouched]) and float(rings.slice[untouched].abs().sum()) == 0.0
+    assert float(rings.digest[blocks, n_steps:].abs().sum()) == 0.0
+    host = rings.digest[ring_index.long(), :n_steps].cpu().numpy()
+    ref = torch.log_softmax(full.float(), dim=-1)                              # (n_steps, g, V)
+    for j, block in enumerate(blocks):
+        view = streams._LogitsView(rings, block)
+        view.window(host[j], sampled[:, j].tolist())
+        for _ in range(n_steps):
+            view.append(None)
+        want = ref[torch.arange(n_steps), j, sampled[:, j]]
+        got = view.gather(sampled[:, j].tolist())
+        assert float((got - want).abs().max()) <= 2e-5
+        for step in range(n_steps):
+            assert view.argmax(step) == int(full[step, j].argmax()), (j, step)
+        assert view.argmax(-1) == int(full[n_steps - 1, j].argmax())
+        # the tokens the fallbacks name: the row's argmax, eot, a timestamp that was not sampled
+        asked = sampled[:, j].tolist()
+        asked[1] = int(full[1, j].argmax())
+        asked[4] = int(tk.eot)
+        asked[5] = ts0 + 123
+        asked[6] = ts0 + 1500
+        want = ref[torch.arange(n_steps), j, torch.tensor(asked)]
+        got = view.gather(asked)
+        assert float((got - want).abs().max()) <= 2e-5, (got, want)
+        lo = ts0 + 41
+        assert view.argmax(3, lo=lo) == int(full[3, j, lo:].argmax()) + lo
+        assert view.argmax(-2, lo=ts0 + 1) == int(full[n_steps - 2, j, ts0 + 1:].argmax()) + ts0 + 1
+        asked[2] = 1234 if 1234 not in (int(sampled[2, j]), int(full[2, j].argmax())) else 1235
+        with pytest.raises(_lib.WtError, match="not kept"):
+            view.gather(asked)
+    assert int(host[1, 2, 3:4].view(np.int32)[0]) == 700
+    return rings, full, sampled, host
+
+
+def test_logits_view_serves_every_token_the_state_machine_can_ask_for(monkeypatch):
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    check_logits_view("cpu")
+
+
+def test_vectorized_timestamp_rules_are_kept_only_when_they_reproduce_the_backend(monkeypatch):
+    """An older backend (no 'timestamps never decrease' rule): the probe notices, the driver keeps the backend's filter."""
+    import whisper_double as W
+    from whisper_timestamped import streams
+    W.install()
+    tk = W.tokenizer.get_tokenizer(True, language="en", task="transcribe")
+    streams._RULES_PROBED.clear()
+    rule = W.decoding.ApplyTimestampRules(tk, 4, 50)
+    task = type("T", (), {"logit_filters": [rule, W.decoding.SuppressTokens([1, 2])]})()
+    out = streams.vectorize_filters(task).logit_filters
+    assert isinstance(out[0], streams.BatchedTimestampRules) and isinstance(out[1], streams.BatchedSuppressTokens)
+
+    class ApplyTimestampRules(W.decoding.ApplyTimestampRules):         # the 2022 rule set: pairs + first position + mass
+        def apply(self, logits, tokens):
+            import torch.nn.functional as F
+            tk_, ts0 = self.tokenizer, self.tokenizer.timestamp_begin
+            logits[:, tk_.no_timestamps] = -float("inf")
+            for k in range(tokens.shape[0]):
+                seq = tokens[k, self.sample_begin:].tolist()
+                last = len(seq) >= 1 and seq[-1] >= ts0
+                penult = len(seq) < 2 or seq[-2] >= ts0
+                if last:
+                    if penult:
+                        logits[k, ts0:] = -float("inf")
+                    else:
+                        logits[k, :tk_.eot] = -float("inf")
+            if tokens.shape[1] == self.sample_begin:
+                logits[:, :ts0] = -float("inf")
+                if self.max_initial_timestamp_index is not None:
+                    logits[:, ts0 + self.max_initial_timestamp_index + 1:] = -float("inf")
+            lp = F.log_softmax(logits.float(), dim=-1)
+            for k in range(tokens.shape[0]):
+                if lp[k, ts0:].logsumexp(dim=-1) > lp[k, :ts0].max():
+                    logits[k, :ts0] = -float("inf")
+    old = ApplyTimestampRules(tk, 4, 50)
+    task = type("T", (), {"logit_filters": [old]})()
+    assert streams.vectorize_filters(task).logit_filters[0] is old
+    streams._RULES_PROBED.clear()

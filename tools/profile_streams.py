@@ -57,3 +57,5 @@ pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("cumulative").print_stats(45)
 st.sort_stats("tottime").print_stats(25)
+for fn in ("_finish_group", "replay_window", "_align_open_segment", "_close_window", "take_result", "launch", "_collect", "commit"):
+    st.sort_stats("cumulative").print_callees(fn)

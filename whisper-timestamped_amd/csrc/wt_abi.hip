@@ -86,6 +86,8 @@ int align_small_tail(const wt_seg_desc *, const wt_seg_desc *, int, float *, boo
                      double *, hipStream_t);
 int logprob_gather_batch(const void *, int, int64_t, int, int, const int32_t *, const uint8_t *, int, const int32_t *, float *,
                          hipStream_t);
+int logprob_digest_streams(const float *, int64_t, int, int, const void *, int, int64_t, const int32_t *, int64_t, int64_t,
+                           const int32_t *, int, int, float *, float *, hipStream_t);
 int qk_rows_batch(const void *const *, const void *const *, int, int, int, int, int64_t, int64_t, int, int, int, float,
                   const int32_t *, const int32_t *, const int32_t *, int, const int32_t *, const int32_t *, const int32_t *, void *,
                   int, int64_t, int64_t, int64_t, hipStream_t);
@@ -229,6 +231,14 @@ int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t row_str
     }
     return wt::logprob_gather_batch(logits, logits_dtype, row_stride, n_out, V, token, nullptr, 0, row_index, out,
                                     (hipStream_t)stream);
+}
+
+int wt_logprob_digest_streams(const float *logits, int64_t row_stride, int n_rows, int V, const void *token, int token_dtype,
+                              int64_t token_stride, const int32_t *ring_index, int64_t ring_rows, int64_t ring_row,
+                              const int32_t *aux_tokens_host, int n_aux, int slice_begin, float *digest, float *slice,
+                              void *stream) {
+    return wt::logprob_digest_streams(logits, row_stride, n_rows, V, token, token_dtype, token_stride, ring_index, ring_rows,
+                                      ring_row, aux_tokens_host, n_aux, slice_begin, digest, slice, (hipStream_t)stream);
 }
 
 int wt_qk_rows_batch(const void *const *q_layers_host, const void *const *k_layers_host, int n_layers, int dtype, int n_batch,

@@ -178,6 +178,145 @@ int logprob_gather_batch(const void *logits, int dtype, int64_t row_stride, int 
 }
 
 // ---------------------------------------------------------------------------
+// B decoder streams (whisper_timestamped/streams.py): what the replayed hook state machine can still ask of a decoder
+// call's filtered logits row, taken when the row is final (the sampler has filtered it in place and the sampled token
+// is known) -- instead of keeping the row itself in a (streams, 449, V) ring (93 MB per stream):
+//   transcribe.py:735,876  log_softmax(row)[sampled token]                     -> rec[0]
+//   transcribe.py:508,729,879  argmax(row)                                      -> rec[3]  (first index of the maximum)
+//   log_softmax(row)[t] for the other tokens the reference's fallbacks name     -> (x[t] - rec[1]) - rec[2] with
+//        x[t] from rec[4..7] (eot, <|notimestamps|> ...) or from the kept slice (any timestamp token)
+//   transcribe.py:535  argmax(row[start_token + 1:]), start_token a timestamp   -> the kept slice row[slice_begin:]
+// One workgroup per row, one streaming pass (the same 128-byte-aligned non-temporal stream as logprob_gather_kernel,
+// same accumulation order: rec[0] is bit for bit what wt_logprob_gather_batch returns for that row and token).
+struct Best {
+    float v;
+    int i;
+};
+__device__ __forceinline__ void best_add(Best &b, float x, int i) {
+    if (x > b.v || (x == b.v && i < b.i)) {
+        b.v = x;
+        b.i = i;
+    }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void logprob_digest_kernel(const float *__restrict__ logits, int64_t row_stride, int V,
+                                                             const TT *__restrict__ token, int64_t token_stride,
+                                                             const int32_t *__restrict__ ring_index, int64_t ring_rows,
+                                                             int64_t ring_row, int4 aux, int n_aux, int slice_begin,
+                                                             float *__restrict__ digest, float *__restrict__ slice) {
+    const float *x = logits + (int64_t)blockIdx.x * row_stride;
+    const int tid = threadIdx.x;
+    MS acc = {-INFINITY, 0.f};
+    Best best = {-INFINITY, 0x7fffffff};
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+    int head = (int)(((128 - (addr & 127)) & 127) / sizeof(float));
+    if (head > V) head = V;
+    const int nvec = (V - head) / 4;
+    const int tail0 = head + nvec * 4;
+    if (tid < head) {
+        const float v = x[tid];
+        ms_add1(acc, v);
+        best_add(best, v, tid);
+    }
+    if (tid < V - tail0) {
+        const float v = x[tail0 + tid];
+        ms_add1(acc, v);
+        best_add(best, v, tail0 + tid);
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *xn = reinterpret_cast<const f4 *>(x + head);
+    int v = tid;
+#define WT_DIGEST4(r, vi)                                   \
+    {                                                       \
+        ms_add4(acc, r.x, r.y, r.z, r.w);                   \
+        const int e = head + 4 * (vi);                      \
+        best_add(best, r.x, e);                             \
+        best_add(best, r.y, e + 1);                         \
+        best_add(best, r.z, e + 2);                         \
+        best_add(best, r.w, e + 3);                         \
+    }
+    for (; v + 768 < nvec; v += 1024) {
+        const f4 r0 = __builtin_nontemporal_load(xn + v), r1 = __builtin_nontemporal_load(xn + v + 256);
+        const f4 r2 = __builtin_nontemporal_load(xn + v + 512), r3 = __builtin_nontemporal_load(xn + v + 768);
+        WT_DIGEST4(r0, v) WT_DIGEST4(r1, v + 256) WT_DIGEST4(r2, v + 512) WT_DIGEST4(r3, v + 768)
+    }
+    for (; v < nvec; v += 256) {
+        const f4 r = xn[v];
+        WT_DIGEST4(r, v)
+    }
+#undef WT_DIGEST4
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MS b;
+        b.m = __shfl_xor(acc.m, o, 64);
+        b.s = __shfl_xor(acc.s, o, 64);
+        acc = ms_merge(acc, b);
+        const float bv = __shfl_xor(best.v, o, 64);
+        const int bi = __shfl_xor(best.i, o, 64);
+        best_add(best, bv, bi);
+    }
+    __shared__ MS part[4];
+    __shared__ Best bpart[4];
+    if ((tid & 63) == 0) {
+        part[tid >> 6] = acc;
+        bpart[tid >> 6] = best;
+    }
+    __syncthreads();
+    const int64_t rec_index = (int64_t)ring_index[blockIdx.x] * ring_rows + ring_row;
+    if (tid == 0) {
+        MS t = ms_merge(ms_merge(part[0], part[1]), ms_merge(part[2], part[3]));
+        Best b = bpart[0];
+        best_add(b, bpart[1].v, bpart[1].i);
+        best_add(b, bpart[2].v, bpart[2].i);
+        best_add(b, bpart[3].v, bpart[3].i);
+        if (b.i == 0x7fffffff) b.i = 0;      // a row of -inf / NaN only: torch.argmax's answer for it
+        const int64_t tok = (int64_t)token[(int64_t)blockIdx.x * token_stride];
+        float xt = -INFINITY;
+        if (tok >= 0 && tok < V) xt = x[tok];
+        float *rec = digest + rec_index * 8;
+        const float ls = logf(t.s);
+        rec[0] = (xt - t.m) - ls;
+        rec[1] = t.m;
+        rec[2] = ls;
+        rec[3] = __int_as_float(b.i);
+        const int a[4] = {aux.x, aux.y, aux.z, aux.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[4 + k] = (k < n_aux && a[k] >= 0 && a[k] < V) ? x[a[k]] : -INFINITY;
+    }
+    if (slice) {
+        const int n = V - slice_begin;
+        float *dst = slice + rec_index * n;
+        for (int e = tid; e < n; e += 256) dst[e] = x[slice_begin + e];
+    }
+}
+
+int logprob_digest_streams(const float *logits, int64_t row_stride, int n_rows, int V, const void *token, int token_dtype,
+                           int64_t token_stride, const int32_t *ring_index, int64_t ring_rows, int64_t ring_row,
+                           const int32_t *aux_host, int n_aux, int slice_begin, float *digest, float *slice, hipStream_t st) {
+    if (!logits || !token || !ring_index || !digest || n_rows < 0 || V <= 0 || row_stride < V || ring_rows <= 0 || ring_row < 0 ||
+        ring_row >= ring_rows || n_aux < 0 || n_aux > 4 || (n_aux > 0 && !aux_host) || (slice && (slice_begin < 0 || slice_begin >= V)) ||
+        (token_dtype != 0 && token_dtype != 1)) {
+        set_error("wt_logprob_digest_streams: bad argument");
+        return WT_E_BADARG;
+    }
+    if (n_rows == 0) return WT_OK;
+    int4 aux = make_int4(-1, -1, -1, -1);
+    if (n_aux > 0) aux.x = aux_host[0];
+    if (n_aux > 1) aux.y = aux_host[1];
+    if (n_aux > 2) aux.z = aux_host[2];
+    if (n_aux > 3) aux.w = aux_host[3];
+    if (token_dtype == 0)
+        hipLaunchKernelGGL(logprob_digest_kernel<int32_t>, dim3(n_rows), dim3(256), 0, st, logits, row_stride, V,
+                           (const int32_t *)token, token_stride, ring_index, ring_rows, ring_row, aux, n_aux, slice_begin, digest, slice);
+    else
+        hipLaunchKernelGGL(logprob_digest_kernel<int64_t>, dim3(n_rows), dim3(256), 0, st, logits, row_stride, V,
+                           (const int64_t *)token, token_stride, ring_index, ring_rows, ring_row, aux, n_aux, slice_begin, digest, slice);
+    WT_HIP(hipGetLastError());
+    return WT_OK;
+}
+
+// ---------------------------------------------------------------------------
 // transcribe.py:1795-1805.  One workgroup per (n_mels, n_cols) window.  Like
 // the reference it looks at the last column first (80 floats: the common "no
 // padding" answer costs one tiny read) and only then walks BACKWARDS, 256

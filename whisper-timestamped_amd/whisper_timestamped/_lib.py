@@ -31,9 +31,9 @@ assert SEG_DTYPE.itemsize == 64
 EXPORTS = ["wt_version", "wt_last_error", "wt_shutdown", "wt_cost_batch", "wt_dtw_batch", "wt_align_batch",
            "wt_find_start_padding_batch", "wt_logprob_gather_batch", "wt_logmel_batch", "wt_capture_rows", "wt_qk_rows",
            "wt_disfluency_batch", "wt_qk_rows_batch", "wt_logprob_gather_rows", "wt_dtw_batch_pattern", "wt_align_batch_v3",
-           "wt_release_stream", "wt_qk_rows_streams", "wt_logmel_pad_batch"]
+           "wt_release_stream", "wt_qk_rows_streams", "wt_logmel_pad_batch", "wt_logprob_digest_streams"]
 WT_STEP_SYMMETRIC1, WT_STEP_NO_EMPTY_SUBWORDS = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 WT_ALIGN_KEEP_COST, WT_ALIGN_NO_FUSED_SMALL_UNITS, WT_ALIGN_ROWS_PER_CLASS = 1, 2, 4
 
 
@@ -75,6 +75,7 @@ def load():
     L.wt_logmel_pad_batch.argtypes = [vp, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp]
     L.wt_qk_rows_streams.argtypes = [vp, vp, i32, i32, i32, i32, i64, i64, i32, i32, i32, f32, vp, vp, vp, i32, vp, vp, i32, i64,
                                      i64, i64, vp]
+    L.wt_logprob_digest_streams.argtypes = [vp, i64, i32, i32, vp, i32, i64, vp, i64, i64, vp, i32, i32, vp, vp, vp]
     if L.wt_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} exports ABI version {L.wt_version()}, this package needs {ABI_VERSION}: rebuild it "
                           f"(`make -C {_PKG_ROOT}/csrc`)")
@@ -347,6 +348,34 @@ def logprob_gather_rows(logits: torch.Tensor, row_index: torch.Tensor, tokens: t
                                            tokens.data_ptr(), out.data_ptr(), st)
     _check(rc, "wt_logprob_gather_rows")
     return out
+
+
+DIGEST_WORDS = 8          # floats per record of wt_logprob_digest_streams (include/wtalign.h)
+
+
+def logprob_digest_streams(rows: torch.Tensor, tokens: torch.Tensor, ring_index: torch.Tensor, digest: torch.Tensor,
+                           slice_ring: torch.Tensor | None, ring_row: int, aux_tokens, slice_begin: int):
+    """One decoder call of g streams: rows (g, V) fp32 (any row stride), tokens (g,) int32 / int64 (any stride): the token
+    sampled from each row.  digest: (n_blocks, ring_rows, 8) fp32, slice_ring: (n_blocks, ring_rows, V - slice_begin) fp32
+    or None; batch row r writes block ring_index[r], row ring_row.  See wt_logprob_digest_streams."""
+    _need_cuda(rows, "rows")
+    assert rows.dim() == 2 and rows.stride(1) == 1 and rows.dtype == torch.float32
+    g, V = rows.shape
+    assert tokens.dim() == 1 and tokens.numel() == g and tokens.dtype in (torch.int32, torch.int64)
+    assert ring_index.dtype == torch.int32 and ring_index.numel() == g
+    assert digest.is_contiguous() and digest.dtype == torch.float32 and digest.shape[-1] == DIGEST_WORDS
+    same_device(rows, tokens, ring_index, digest, slice_ring)
+    if slice_ring is not None:
+        assert slice_ring.is_contiguous() and slice_ring.dtype == torch.float32 and \
+            slice_ring.shape == (digest.shape[0], digest.shape[1], V - slice_begin), (slice_ring.shape, digest.shape, V, slice_begin)
+    aux = (ctypes.c_int32 * max(1, len(aux_tokens)))(*[int(t) for t in aux_tokens])
+    with on_device(rows) as st:
+        rc = load().wt_logprob_digest_streams(rows.data_ptr(), rows.stride(0) if g > 1 else V, g, V, tokens.data_ptr(),
+                                              1 if tokens.dtype == torch.int64 else 0, tokens.stride(0) if g > 1 else 1,
+                                              ring_index.data_ptr(), digest.shape[1], int(ring_row), aux, len(aux_tokens),
+                                              int(slice_begin), digest.data_ptr(),
+                                              slice_ring.data_ptr() if slice_ring is not None else None, st)
+    _check(rc, "wt_logprob_digest_streams")
 
 
 def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring: torch.Tensor, row_begin=None, row_end=None,

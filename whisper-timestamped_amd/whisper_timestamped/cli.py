@@ -164,7 +164,8 @@ def cli(argv=None):
             transcribe_timestamped(model, audio_path, temperature=temperature,
                                    plot_word_alignment=outname if (outname and plot) else plot, **args)
         if not output_dir:
-            if not args["verbose"]:
+            # (the B-stream path prints no segments while it decodes: its results are always dumped, verbose or not)
+            if not args["verbose"] or results is not None:
                 json.dump(filtered_keys(result), sys.stdout, indent=2, ensure_ascii=False)
             continue
         segments = result["segments"]

@@ -62,6 +62,17 @@ FUSED_ATTENTION = True
 DEFER_ALIGNMENT = True
 
 
+class _RowInTheRing:
+    """`outs` of a replayed decoder call (streams.py): the session only ever takes `outs[0, -1]` of it, to append a row
+    whose digest the driver has already written into the stream's block."""
+
+    def __getitem__(self, key):
+        return None
+
+
+_ROW_IN_THE_RING = _RowInTheRing()
+
+
 class EfficientSession:
     def __init__(self, model, whisper_options, *, remove_punctuation_from_words, compute_word_confidence,
                  include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
@@ -241,13 +252,21 @@ class EfficientSession:
         self.segment_tokens[-1].extend(toks)
         self.open_rows.extend(range(self.row_next, self.row_next + n))
         self.row_next += n
-        self.window_inputs.extend([t] for t in toks)
+        self.window_inputs.extend(toks)           # (only the first entry of a window -- its prompt -- is ever read back)
         self.ctx_len += n
         self.window_tokens_nosot.extend(toks)
         self.sot_index = None
         self.logits.n += n - 1                    # every call of the run but the last has been committed by its successor
         self.last_chunk_token = None
         self.pending_logits = (row_in_ring, False)
+
+    def replay_prompt_logits(self, no_speech_prob):
+        """Replay (streams.py): `hook_decoder_logits` for the prompt call of a window, with what it would read of the
+        call's logits handed over -- the no-speech probability, computed for all streams of the loop at once by the
+        backend's own decoder loop (softmax of the <|startoftranscript|> position: the expression of T.py:861-864)."""
+        if self.sot_index is not None and self.no_speech_prob is None:
+            self.no_speech_prob = no_speech_prob
+        self.hook_decoder_logits(None, None, _ROW_IN_THE_RING)
 
     def hook_cross_attention(self, index, layer, ins, outs):
         assert isinstance(outs, tuple) and len(outs) == 2, "whisper seems to be outdated, please update it"

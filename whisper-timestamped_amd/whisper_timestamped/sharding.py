@@ -264,7 +264,7 @@ def transcribe_recordings(model, audios, dist=None, broadcast_weights: bool = Fa
 # streams would, with no change to the backend's loop and therefore to its output.  No collective anywhere: a job queue
 # in, result dictionaries out.
 def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options, barrier, out_queue, on_item, warmup,
-                 streams=0, on_batch=None):
+                 streams=0, on_batch=None, barrier_timeout=600.0):
     """`mine` = the indices (into the caller's list) of this worker's recordings, `my_audios` = those recordings only."""
     import time
     import os
@@ -279,9 +279,11 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
     from .transcribe import transcribe_batch, transcribe_timestamped
     model = load_model(dev)
     if warmup and mine and streams and streams > 1:
+        # ONE recording through the B-stream driver (allocations, GEMM plans, arenas, the self-checks) -- not the worker's
+        # whole batch: the workers' warm-ups would otherwise differ by whole batches at the barrier below
         if on_batch is not None:
-            on_batch(mine)
-        transcribe_batch(model, my_audios, max_streams=streams, **options)
+            on_batch(mine[:1])
+        transcribe_batch(model, my_audios[:1], max_streams=streams, **options)
     elif warmup and mine:                        # allocations, GEMM plans, the library's arenas: before the common start
         if on_item is not None:
             on_item(mine[0])
@@ -289,7 +291,7 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
     if on_gpu:
         torch.cuda.synchronize(dev)
     if barrier is not None:
-        barrier.wait(timeout=600)                # (BrokenBarrierError when the parent aborted it: a sibling died)
+        barrier.wait(timeout=barrier_timeout)    # (BrokenBarrierError when the parent aborted it: a sibling died)
     t0 = time.perf_counter()
     res = []
     if streams and streams > 1:                  # the worker's recordings as decoder streams (streams.py)
@@ -307,7 +309,7 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
 
 
 def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, on_item=None, warmup: bool = False,
-                    return_timing: bool = False, streams: int = 0, on_batch=None, **options):
+                    return_timing: bool = False, streams: int = 0, on_batch=None, barrier_timeout: float = 600.0, **options):
     """transcribe_timestamped() of every recording in `audios` (1-D fp32 tensors / arrays at 16 kHz, or paths) on
     `workers_per_gpu` worker processes per GPU.  `load_model(device)` -> the model; it runs inside each worker and must
     be picklable (a module-level function), as must `on_item(index)` (called in the worker before item `index`).
@@ -329,12 +331,14 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     queue = ctx.Queue()
     # every worker is sent ITS recordings only (spawn pickles the arguments: W x the whole list otherwise)
     procs = [ctx.Process(target=_many_worker, args=(r, n_workers, devices, load_model, [audios[i] for i in order[r]], order[r],
-                                                    options, barrier, queue, on_item, warmup, streams, on_batch))
+                                                    options, barrier, queue, on_item, warmup, streams, on_batch,
+                                                    barrier_timeout))
              for r in range(n_workers)]
     for p in procs:
         p.daemon = True           # (a worker never outlives the process that asked for it)
         p.start()
     got, slowest = {}, 0.0
+    failed = False
     try:
         for _ in procs:
             while True:
@@ -350,6 +354,7 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
     except BaseException:
         # a worker that died before the barrier would leave its siblings waiting there for good: break the barrier and
         # stop everybody at once instead of joining blocked workers one by one
+        failed = True
         barrier.abort()
         for p in procs:
             if p.is_alive():
@@ -357,7 +362,7 @@ def transcribe_many(load_model, audios, workers_per_gpu: int = 8, devices=None, 
         raise
     finally:
         for p in procs:
-            p.join(timeout=5)
+            p.join(timeout=5 if failed else 60)       # (success: a worker is tearing its HIP context down -- give it time)
             if p.is_alive():
                 p.terminate()
     assert sorted(got) == list(range(len(audios)))

@@ -59,6 +59,14 @@ N_SAMPLES = 30 * SAMPLE_RATE
 # loop, in row order, right before it starts
 ON_GROUP_DECODE = None
 LAST_RUN = {}
+# how often a stream's session asked for something other than the sampled token's log-probability (the reference's
+# fallbacks for a stuck decoder): tests / diagnostics
+# Bucket admission (0 / 1 = off): streams share a decoder loop only when their prompts have the same LENGTH.  A stream
+# whose length fewer than HOLD_FOR_BUCKET streams share this round may sit ONE round out -- next round the recordings
+# admitted meanwhile (first windows: equal prompts) or another held stream may join it.  Never two rounds in a row, and
+# never when that would leave the round empty.  Results do not depend on it (a window's result depends on its own prompt).
+HOLD_FOR_BUCKET = 0
+FALLBACK_READS = {"argmax": 0, "argmax_over_later_timestamps": 0, "logprob_of_another_token": 0}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -79,15 +87,19 @@ class _QKView:
 
 
 class _LogitsView:
-    """What an EfficientSession needs of a LogitsRing, on one stream's block.  The rows are written by the driver (all
-    streams of a decoder call at once); ``append`` only advances the stream's own count.  ``gather`` is served from the
-    log-probabilities the driver computed for ALL streams of the loop in one launch, as long as the tokens asked for
-    are the tokens that were sampled (else -- the reference's fallbacks for a stuck decoder -- by the kernel)."""
+    """What an EfficientSession needs of a LogitsRing, for one stream of the B-stream driver.  No logits row is kept: when
+    a decoder call's rows are final, ONE launch for all streams of the call (wt_logprob_digest_streams) takes from each
+    row what the hook state machine can still ask of it -- the sampled token's log-probability (T.py:735), the row's
+    argmax (T.py:508,729,879), its max / log-sum-exp and the raw logits of <|endoftext|>, <|notimestamps|> and of every
+    timestamp token (T.py:535 and the fallback tokens of a stuck decoder) -- 32 bytes + 6 KB per row instead of 207 KB.
+    The driver hands over the digests of the stream's window as ONE host array per decoder loop (`host`), so `gather`
+    and `argmax` are host reads; only a timestamp token that was not the sampled one goes back to the device slice."""
 
-    def __init__(self, buf):
-        self.buf = buf                      # (capacity, V)
+    def __init__(self, rings, block):
+        self.rings, self.block = rings, block
         self.n = 0
-        self.known = None                   # (tokens, logprobs) of the loop just decoded: host lists / fp32 array
+        self.host = None                    # (n_calls, 8) fp32: this window's digest records, on the host
+        self.sampled = None                 # int64[n_calls]: the token sampled at each call
 
     def reset(self):
         self.n = 0
@@ -98,38 +110,83 @@ class _LogitsView:
     def __len__(self):
         return self.n
 
+    def window(self, host, sampled):
+        self.host, self.sampled = host, np.asarray(sampled, dtype=np.int64)
+
     def argmax(self, row, lo=0):
         if row < 0:
             row += self.n
-        return int(torch.argmax(self.buf[row, lo:]).item()) + lo
+        if lo == 0:
+            FALLBACK_READS["argmax"] += 1
+            return int(self.host[row, 3:4].view(np.int32)[0])
+        FALLBACK_READS["argmax_over_later_timestamps"] += 1
+        r = self.rings
+        assert lo >= r.slice_begin, f"argmax(row, lo={lo}): only the timestamp slice of a row is kept"
+        return int(torch.argmax(r.slice[self.block, row, lo - r.slice_begin:]).item()) + lo
+
+    def _logprob_of(self, row, tok):
+        """log_softmax(row)[tok] for a token other than the sampled one (the reference's fallbacks for a stuck decoder)."""
+        d, r = self.host[row], self.rings
+        FALLBACK_READS["logprob_of_another_token"] += 1
+        if tok == int(d[3:4].view(np.int32)[0]):
+            x = d[1]
+        elif tok in r.aux_tokens:
+            x = d[4 + r.aux_tokens.index(tok)]
+        elif tok >= r.slice_begin:
+            x = np.float32(r.slice[self.block, row, tok - r.slice_begin].item())
+        else:
+            raise _lib.WtError(f"streams: the log-probability of token {tok} at step {row} was asked for, which is neither the sampled "
+                               f"token, the most likely one, a special token nor a timestamp: not kept by the B-stream driver")
+        return np.float32(np.float32(x - d[1]) - d[2])
 
     def gather(self, tokens):
         n = len(tokens)
-        assert n <= self.n
-        if self.known is not None and list(self.known[0][:n]) == [int(t) for t in tokens]:
-            return torch.from_numpy(np.array(self.known[1][:n], dtype=np.float32))
-        return _lib.logprob_gather(self.buf[:n], torch.as_tensor(tokens, dtype=torch.int32))
+        assert n <= self.n and self.host is not None and n <= len(self.host)
+        tok = np.asarray(tokens, dtype=np.int64)
+        out = self.host[:n, 0].copy()
+        for i in np.nonzero(tok != self.sampled[:n])[0]:
+            out[i] = self._logprob_of(int(i), int(tok[i]))
+        return torch.from_numpy(out)
 
 
 class StreamRings:
-    """(B, A_sel, capacity, n_ctx) QK logits of the alignment heads + (B, capacity + 1, V) filtered logits."""
+    """(B, A_sel, capacity, n_ctx) QK logits of the alignment heads + per decoder call and stream a 32-byte digest of the
+    filtered logits row and its timestamp slice ((B, capacity, 8) and (B, capacity, V - timestamp_begin) fp32).
+    capacity = the decoder calls a window can take (sample_len + 1)."""
 
-    def __init__(self, model, alignment_heads, hooked_blocks, n_streams, dtype):
+    def __init__(self, model, alignment_heads, hooked_blocks, n_streams, dtype, sample_len=None, tokenizer=None):
         dev = model.device
         dims = model.dims
         self.device = dev
-        self.n_streams, self.capacity, self.n_ctx = n_streams, dims.n_text_ctx, dims.n_audio_ctx
+        calls = min(dims.n_text_ctx, int(sample_len or dims.n_text_ctx // 2) + 1)
+        self.n_streams, self.capacity, self.n_ctx = n_streams, calls, dims.n_audio_ctx
         per_layer, self.n_slots = layer_head_slots(head_pairs(alignment_heads), len(hooked_blocks), dims.n_text_head)
         self.used = [l for l, (h, _) in enumerate(per_layer) if h]
         sel = [(i, h, s) for i, l in enumerate(self.used) for h, s in zip(*per_layer[l])]
         self.sel = tuple(torch.tensor([x[k] for x in sel], dtype=torch.int32, device=dev) for k in range(3))
         self.n_sel = len(sel)
         self.qk = torch.zeros((n_streams, max(self.n_slots, 1), self.capacity, self.n_ctx), dtype=dtype, device=dev)
-        self.logits = torch.empty((n_streams, self.capacity + 1, dims.n_vocab), dtype=torch.float32, device=dev)
+        tk = tokenizer
+        self.slice_begin = int(tk.timestamp_begin)
+        self.aux_tokens = [int(tk.eot)] + ([int(tk.no_timestamps)] if tk.no_timestamps is not None else [])
+        self.digest = torch.zeros((n_streams, self.capacity, _lib.DIGEST_WORDS), dtype=torch.float32, device=dev)
+        self.slice = torch.zeros((n_streams, self.capacity, dims.n_vocab - self.slice_begin), dtype=torch.float32, device=dev)
         self._dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[dtype]
         self._lib = _lib.load()
         import ctypes as C
         self._qp, self._kp = (C.c_void_p * len(self.used))(), (C.c_void_p * len(self.used))()
+
+    @staticmethod
+    def bytes_per_stream(model, alignment_heads, hooked_blocks, dtype, sample_len, tokenizer):
+        dims = model.dims
+        calls = min(dims.n_text_ctx, int(sample_len or dims.n_text_ctx // 2) + 1)
+        _, n_slots = layer_head_slots(head_pairs(alignment_heads), len(hooked_blocks), dims.n_text_head)
+        item = 2 if dtype == torch.float16 else 4
+        return calls * (max(n_slots, 1) * dims.n_audio_ctx * item + 4 * (_lib.DIGEST_WORDS + dims.n_vocab - int(tokenizer.timestamp_begin)))
+
+    def write_digest(self, rows, tokens, ring_index, step):
+        """rows (g, V): a decoder call's last-position logits as the sampler left them; tokens (g,): what it sampled."""
+        _lib.logprob_digest_streams(rows, tokens, ring_index, self.digest, self.slice, step, self.aux_tokens, self.slice_begin)
 
     def write_qk(self, q_layers, k_layers, ring_index, row):
         """The LAST query row of every selected head, for every stream of the call: q (g, n_q, D), K (g, n_ctx, D) per
@@ -272,9 +329,62 @@ class BatchedSuppressTokens:
         logits.index_fill_(1, self._idx, -np.inf)
 
 
+_RULES_PROBED = {}        # backend filter class -> does BatchedTimestampRules reproduce it? (probed once per process)
+
+
+def _rules_match_backend(rule):
+    """The backend's own ApplyTimestampRules and BatchedTimestampRules on a small probe of random token histories (no
+    timestamp yet, open and closed pairs, the first sampled position) and logits: the batched form is used only if the
+    results are identical -- an older openai-whisper without the 'timestamps never decrease' rule, or a newer one with
+    rules this file does not know, keeps its own filter (as the FUSED_ATTENTION / REUSE_DECODER_LOGITS self-checks do)."""
+    key = type(rule)
+    if key in _RULES_PROBED:
+        return _RULES_PROBED[key]
+    ok = True
+    try:
+        tk = rule.tokenizer
+        ts0 = int(tk.timestamp_begin)
+        V = ts0 + 1501
+        rng = np.random.RandomState(1)
+        g = torch.Generator().manual_seed(1)
+        mine = BatchedTimestampRules.like(rule)
+        sb = int(rule.sample_begin)
+        for n in (0, 1, 2, 3, 6, 17):
+            rows = []
+            for _ in range(6):
+                seq, t = [], int(rng.randint(0, 60))
+                while len(seq) < n:
+                    kind = rng.randint(4) if seq else 0
+                    if kind == 0:
+                        t += int(rng.randint(0, 40))
+                        seq.append(ts0 + t)
+                    elif kind == 1 and seq[-1] >= ts0:
+                        seq.append(seq[-1] if rng.rand() < 0.5 else ts0 + t + int(rng.randint(0, 9)))
+                    else:
+                        seq.append(int(rng.randint(300, 40000)))
+                rows.append([11] * sb + seq)
+            tokens = torch.tensor(rows)
+            logits = torch.randn((len(rows), V), generator=g) * 3
+            logits[:, ts0:] += float(rng.choice([-6.0, 0.0, 6.0]))
+            a, b = logits.clone(), logits.clone()
+            rule.apply(a, tokens)
+            mine.apply(b, tokens)
+            if not torch.equal(a, b):
+                ok = False
+                break
+    except Exception as e:                                 # noqa: BLE001 -- a backend this probe cannot drive keeps its own filter
+        logger.debug(f"whisper_timestamped: timestamp-rule probe failed ({e!r})")
+        ok = False
+    if not ok:
+        logger.warning("whisper_timestamped: this backend's ApplyTimestampRules differs from the batched form "
+                       "(another openai-whisper version?): the B-stream driver keeps the backend's own row-by-row filter")
+    _RULES_PROBED[key] = ok
+    return ok
+
+
 def vectorize_filters(task):
     if VECTORIZED_TIMESTAMP_RULES:
-        task.logit_filters = [BatchedTimestampRules.like(f) if type(f).__name__ == "ApplyTimestampRules"
+        task.logit_filters = [BatchedTimestampRules.like(f) if type(f).__name__ == "ApplyTimestampRules" and _rules_match_backend(f)
                               else BatchedSuppressTokens(f.suppress_tokens) if type(f).__name__ == "SuppressTokens" and hasattr(f, "suppress_tokens")
                               else f for f in task.logit_filters]
     return task
@@ -297,16 +407,17 @@ _IN_RING = _RowAlreadyInTheRing()
 class _Recorder:
     """Forward hooks for the duration of one ``_main_loop`` over g streams.  Per decoder call it keeps the input token
     ids (host), writes the QK rows of all streams (one launch) and, one call later -- when the sampler has filtered the
-    previous call's last-position logits in place -- copies those (g, V) rows into the logits ring."""
+    previous call's last-position logits in place and the tokens it sampled are this call's input -- takes the digest
+    of those (g, V) rows (one launch: StreamRings.write_digest)."""
 
     def __init__(self, model, rings: StreamRings, hooked_blocks, ring_index, verify: bool):
         self.model, self.rings, self.hooked_blocks = model, rings, hooked_blocks
         self.ring_index = ring_index                       # device int32[g]
         self.ring_index_long = ring_index.long()
         self.calls = []                                    # per decoder call: list of g token lists
-        self.first_outs = None                             # (g, L, V) logits of the prompt call
         self.pending = None
         self.capture = True                                # False during language detection (T.py:828: not started)
+        self.lang_outs = None
         self.verify = verify
         self.verify_rows = None
         self.verified = None
@@ -339,7 +450,7 @@ class _Recorder:
 
     # --- hooks, in firing order within one decoder call
     def on_tokens(self, layer, ins, outs):
-        self.commit()
+        self.commit(ins[0][:, -1])                         # this call's input = what the sampler drew from the pending rows
         self.calls.append(ins[0].tolist())                 # the per-step host read whisper's own loop needs anyway
 
     def on_last_cross_attention(self, layer, ins, outs):
@@ -358,20 +469,21 @@ class _Recorder:
             self.verify_rows = (outs[:, -1, :] @ e).float()
 
     def on_logits(self, layer, ins, outs):
-        if len(self.calls) == 1:
-            self.first_outs = outs
+        if not self.capture:
+            self.lang_outs = outs                          # language detection: (n, 1, V), read by every new stream's session
         self.pending = outs
 
-    def commit(self):
-        """The previous call's last-position rows are final (the sampler filtered them in place): into the ring."""
+    def commit(self, sampled):
+        """The previous call's last-position rows are final (the sampler filtered them in place) and `sampled` (g,) holds
+        the tokens drawn from them: their digests into the ring.  The rows themselves are not kept."""
         if self.pending is None or not self.capture:
             self.pending = None
             return
         rows = self.pending[:, -1]
         step = len(self.calls) - 1
         if self.verify and step == 0 and self.verify_rows is not None:
-            self.verified = (rows, self.verify_rows)       # compared by the driver with the filters applied
-        self.rings.logits[self.ring_index_long, step] = rows
+            self.verified = (rows.clone(), self.verify_rows)       # compared by the driver with the filters applied
+        self.rings.write_digest(rows, sampled, self.ring_index, step)
         self.pending = None
 
     def check_fused_rows(self, row):
@@ -417,6 +529,7 @@ class _Stream:
         self.prompt_reset_since = 0
         self.done = False
         self.block = index                  # its block of the shared rings (the driver assigns it on admission)
+        self.held = 0                       # rounds in a row this stream sat out waiting for streams with its prompt length
         # the window being decoded
         self.segment_size = 0
         self.task = None
@@ -604,7 +717,18 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     top_layers = session_kwargs["word_alignment_most_top_layers"]
     top = n_blocks if top_layers is None else min(top_layers, n_blocks)
     hooked_blocks = list(range(n_blocks - top, n_blocks))
-    rings = StreamRings(model, session_kwargs["alignment_heads"], hooked_blocks, S, efficient.RING_DTYPE)
+    tk0 = backend.get_tokenizer(model, task=opts["task"], language=opts["language"] or "en")     # (special-token ids: the same for every language)
+    per_stream = StreamRings.bytes_per_stream(model, session_kwargs["alignment_heads"], hooked_blocks, efficient.RING_DTYPE,
+                                              opts.get("sample_len"), tk0)
+    if dev.type == "cuda":
+        # the rings must fit: S streams x (QK rows + digests) next to the model, its KV caches and the whole-file log-mels
+        fit = int(0.5 * torch.cuda.mem_get_info(dev)[0] // max(per_stream, 1))
+        if fit < S:
+            logger.warning(f"whisper_timestamped: {S} decoder streams need {S * per_stream / 2**30:.1f} GiB of ring memory; "
+                           f"{max(fit, 1)} fit the free device memory -- the other recordings are admitted as streams finish")
+            S = max(1, fit)
+    rings = StreamRings(model, session_kwargs["alignment_heads"], hooked_blocks, S, efficient.RING_DTYPE,
+                        sample_len=opts.get("sample_len"), tokenizer=tk0)
     sink = _Sink(default_workspace(dev))
     streams = [None] * N                                  # by recording
     free = list(range(S))
@@ -640,9 +764,9 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                 finally:
                     rec.remove()
                 languages = [max(p, key=p.get) for p in probs]
-                lang_events = (first, rec.calls[0], rec.first_outs, _lib.HostCopy(_lib.find_start_padding(first.float())))
+                lang_events = (first, rec.calls[0], rec.lang_outs, _lib.HostCopy(_lib.find_start_padding(first.float())))
         for j, ((i, block), mel, lang) in enumerate(zip(new, mels, languages)):
-            session = EfficientSession(model, dict(opts), ring=_QKView(rings.qk[block]), logits=_LogitsView(rings.logits[block]),
+            session = EfficientSession(model, dict(opts), ring=_QKView(rings.qk[block]), logits=_LogitsView(rings, block),
                                        sink=sink, **session_kwargs)
             tk = backend.get_tokenizer(model, task=opts["task"], language=lang)
             prompt0 = tk.encode(" " + opts["initial_prompt"].strip()) if opts.get("initial_prompt") is not None else []
@@ -662,7 +786,8 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
         st.mel = None
         free.append(st.block)
 
-    rounds = groups = 0
+    rounds = groups = held_total = 0
+    loop_sizes = []
     verify = efficient.REUSE_DECODER_LOGITS == "auto"
     fused_checked = False
     try:
@@ -678,10 +803,8 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         continue
                     break
                 rounds += 1
-                # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
-                mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
-                pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
-                for j, st in enumerate(act):
+                # ---- every active stream's prompt for its next window (the backend's own DecodingTask builds it)
+                for st in act:
                     kwargs = {k: opts[k] for k in decode_keys if k in opts}
                     kwargs["language"] = st.language
                     kwargs["prompt"] = st.all_tokens[st.prompt_reset_since:]
@@ -691,6 +814,23 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         kwargs.pop("best_of", None)
                     st.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
                     st.initial_tokens = list(st.task.initial_tokens)
+                # ---- bucket admission: a stream whose prompt length nobody shares this round may sit one round out
+                if HOLD_FOR_BUCKET > 1 and len(act) > 1:
+                    sizes = {}
+                    for st in act:
+                        sizes[len(st.initial_tokens)] = sizes.get(len(st.initial_tokens), 0) + 1
+                    lone = [st for st in act if sizes[len(st.initial_tokens)] < HOLD_FOR_BUCKET and st.held == 0]
+                    if lone and len(lone) < len(act):
+                        for st in lone:
+                            st.held += 1
+                        held_total += len(lone)
+                        act = [st for st in act if st not in lone]
+                for st in act:
+                    st.held = 0
+                # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
+                mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
+                pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
+                for j, st in enumerate(act):
                     st.session.hook_mel(None, (mel_batch[j:j + 1],), None, pad_handle=_SliceOfCopy(pad, j))
                     st.session.on_tokens(list(st.initial_tokens))
                 sink.launch()
@@ -700,6 +840,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                     by_len.setdefault(len(st.initial_tokens), []).append(j)
                 for L, members in by_len.items():
                     groups += 1
+                    loop_sizes.append(len(members))
                     grp = [act[j] for j in members]
                     if ON_GROUP_DECODE is not None:
                         ON_GROUP_DECODE([st.index for st in grp])
@@ -713,7 +854,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         feats = task._get_audio_features(mel_batch[members])
                         tokens0 = torch.tensor([st.initial_tokens for st in grp], device=dev)
                         tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
-                        rec.commit()
+                        rec.commit(tokens[:, -1])             # the last call's rows and what was sampled from them
                     finally:
                         rec.remove()
                     fused_checked = True
@@ -729,19 +870,23 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
         sink.in_flight = []
     LAST_RUN.clear()
     LAST_RUN.update(streams=N, ring_blocks=S, admissions=admissions, rounds=rounds, decoder_loops=groups,
-                    alignment_launch_sets=sink.launch_sets)
+                    alignment_launch_sets=sink.launch_sets, streams_per_loop=loop_sizes, windows_held_one_round=held_total,
+                    ring_bytes=int(rings.qk.numel() * rings.qk.element_size() + 4 * (rings.digest.numel() + rings.slice.numel())))
     return out
 
 
 def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temperature, opts, w, verify):
-    """After a batched decoder loop: results per stream, the chosen-token log-probabilities of all streams in one launch,
-    the loop's recorded calls replayed into every stream's session, the backend's window bookkeeping."""
+    """After a batched decoder loop: results per stream, every stream's digest records of the loop in ONE host copy
+    (the chosen-token log-probabilities among them: computed call by call while the loop ran), the loop's recorded
+    calls replayed into every stream's session, the backend's window bookkeeping."""
     tk = task.tokenizer
     g = len(grp)
     L = task.sample_begin
+    n_calls = len(rec.calls)
+    # one copy for the group: (g, n_calls, 8) digest records -> page-locked host memory
+    digests = _lib.HostCopy(rings.digest[rec.ring_index_long, :n_calls])
     tokens_f, sums = task.decoder.finalize(tokens.reshape(g, 1, -1), sum_logprobs.reshape(g, 1))
     rows_host = tokens.tolist()
-    n_calls = len(rec.calls)
     # each stream takes part in the calls up to the one whose sample was <|endoftext|> (later calls feed it eot)
     sampled, results = [], []
     for i, s in enumerate(grp):
@@ -755,10 +900,11 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         smp = rows_host[i][L:]                               # what the sampler returned at calls 0, 1, ...
         n_mine = min(n_calls, (smp.index(tk.eot) + 1) if tk.eot in smp else len(smp))
         sampled.append(smp[:n_mine])
-    # the sampler's in-place filtering must be there (<|notimestamps|> is always suppressed) -- one read for the group
-    idx = rec.ring_index_long
+    host = digests.wait().numpy().reshape(g, n_calls, _lib.DIGEST_WORDS)
+    # the sampler's in-place filtering must be there (<|notimestamps|> is always suppressed) -- read from the digests
     if tk.no_timestamps is not None:
-        if not bool(torch.isinf(rings.logits[idx, 0, tk.no_timestamps]).all()):
+        k = 4 + rings.aux_tokens.index(int(tk.no_timestamps))
+        if not bool(np.isneginf(host[:, 0, k]).all()):
             raise RuntimeError("streams: this backend does not filter the decoder's logits in place; use the one-stream path "
                                "(whisper_timestamped.efficient.REUSE_DECODER_LOGITS = False)")
     if verify and rec.verified is not None:
@@ -773,23 +919,15 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         if not (bool(torch.equal(fin, torch.isfinite(got))) and bool(((got[fin] - want[fin]).abs() <= tol).all())):
             raise RuntimeError("streams: the decoder's logits do not carry the sampler's filtering (or differ from the "
                                "re-projected ones); use the one-stream path")
-    # ONE gather for every (stream, call): log_softmax(row)[sampled token]
-    cap1 = rings.logits.shape[1]
-    row_index = torch.tensor([int(s.block) * cap1 + k for i, s in enumerate(grp) for k in range(len(sampled[i]))], dtype=torch.int32)
-    tok = torch.tensor([t for smp in sampled for t in smp], dtype=torch.int32)
-    flat = rings.logits.view(-1, rings.logits.shape[-1])
-    lps = _lib.logprob_gather_rows(flat, row_index.to(flat.device), tok.to(flat.device)).cpu().numpy()
-    o = 0
-    for i, s in enumerate(grp):
-        n = len(sampled[i])
-        s.session.logits.known = (sampled[i], lps[o:o + n])
-        o += n
     # replay: call 0 was the prompt (its token half ran before the loop); then the remaining calls of each stream
+    no_speech = [float(x) for x in no_speech]
     for i, s in enumerate(grp):
         ses = s.session
         assert rec.calls[0][i] == s.initial_tokens
-        ses.hook_decoder_logits(None, None, rec.first_outs[i:i + 1])
-        mine = [rec.calls[k][i][0] for k in range(1, len(sampled[i]))]     # the one token fed at calls 1, 2, ...
+        n = len(sampled[i])
+        ses.logits.window(host[i, :n], sampled[i])
+        ses.replay_prompt_logits(no_speech[i])
+        mine = sampled[i][:n - 1]                             # the one token fed at calls 1, 2, ...: what call k - 1 sampled
         ts0, k, n = ses.tokenizer.timestamp_begin, 0, len(mine)
         while k < n:
             e = k
@@ -803,4 +941,4 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
             ses.hook_decoder_logits(None, None, _IN_RING)
             k += 1
         out_tokens, avg_logprob = results[i]
-        s.take_result(out_tokens, avg_logprob, float(no_speech[i]), temperature, opts, w)
+        s.take_result(out_tokens, avg_logprob, no_speech[i], temperature, opts, w)

@@ -277,12 +277,13 @@ def transcribe_batch(model, audios, max_streams=32, **options):
         return []
     plan = _plan(model, a)
     from . import streams
+    # (one recording at a time: the model _plan has already loaded -- a name or a path is not read from disk again per recording)
     if not streams.supports(plan["whisper_options"], plan["vad"], plan["naive_approach"], a["plot_word_alignment"]):
-        return [transcribe_timestamped(model, audio, **options) for audio in audios]
+        return [transcribe_timestamped(plan["model"], audio, **options) for audio in audios]
     missing = streams.backend_missing()
     if missing:
         logger.warning(f"transcribe_batch: this ASR backend lacks {', '.join(missing)}: decoding one stream at a time")
-        return [transcribe_timestamped(model, audio, **options) for audio in audios]
+        return [transcribe_timestamped(plan["model"], audio, **options) for audio in audios]
     if a["seed"] is not None:
         torch.manual_seed(a["seed"])
         torch.cuda.manual_seed_all(a["seed"])
