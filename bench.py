@@ -439,6 +439,84 @@ def run_step(w, ev=None, streams=None):
     w["host_result"].copy_(w["result"], non_blocking=True)
 
 
+# How the stages of ONE batch share the chip when several batches are in flight (--schedule; tools/overlap_matrix.py timed
+# the candidates on the current kernels: profiles/r5*_overlap_matrix.json).  "serial": every batch on one stream, stages in
+# order (rounds 2-4).  "hilo": per batch a HIGH-priority HIP stream for the kernels that cannot use the chip's bandwidth
+# (stft_mel: VALU/LDS-bound; dtw_kernel: a latency chain on 32 CUs) and a LOW-priority one for the HBM-bound ones (cost,
+# log-prob gather): the dispatcher places the high-priority workgroups first, the bandwidth kernels fill what is left --
+# each HBM-bound kernel runs beside a compute-bound one of the same batch, and the second batch fills the gaps.
+STAGE_ORDER = ["logmel", "cost", "dtw", "logprob"]
+SCHEDULES = {
+    "serial": None,
+    "hilo": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo", "low")},
+             "order": STAGE_ORDER},
+    "dtw_hi": {"assign": {"logmel": ("lo", "low"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo", "low")},
+               "order": STAGE_ORDER},
+    "two_streams": {"assign": {"logmel": ("hi", "normal"), "dtw": ("hi", "normal"), "cost": ("lo", "normal"), "logprob": ("lo", "normal")},
+                    "order": STAGE_ORDER},
+}
+
+
+def stream_priorities():
+    """{"low": least, "normal": 0, "high": greatest} of hipDeviceGetStreamPriorityRange (MI355X / ROCm 7.2: 1, 0, -1)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    rc = hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi))
+    assert rc == 0, f"hipDeviceGetStreamPriorityRange failed: {rc}"
+    return {"low": lo.value, "normal": 0, "high": hi.value}
+
+
+def priority_stream(dev, priority):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithPriority(ctypes.byref(st), ctypes.c_uint(1), ctypes.c_int(priority))     # 1 = hipStreamNonBlocking
+    assert rc == 0, f"hipStreamCreateWithPriority failed: {rc}"
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
+def plan_streams(dev, plan):
+    prio = stream_priorities()
+    out = {}
+    for stage in plan["order"]:
+        key, level = plan["assign"][stage]
+        if key not in out:
+            out[key] = priority_stream(dev, prio[level])
+    return out
+
+
+def run_step_plan(w, plan, streams):
+    """One pass of the hot path with its stages on the streams of `plan`.  The DTW waits for its cost stage; a buffer set's
+    NEXT step waits for what still reads its buffers (the DTW reads the cost matrix the next cost stage overwrites, the
+    result copy reads the record the next DTW / log-prob gather overwrite); the result copy waits for every stage.
+    Returns the stream the copy was queued on (the step is complete when that stream is)."""
+    calls = w.setdefault("_calls", _stage_calls(w))
+    ev = w.setdefault("_plan_events", {})
+    for stage in plan["order"]:
+        st = streams[plan["assign"][stage][0]]
+        if stage == "dtw":
+            st.wait_event(ev["cost"])
+        if stage == "cost" and "dtw" in ev:
+            st.wait_event(ev["dtw"])
+        if (stage in ("dtw", "logprob") or (stage == "cost" and "dtw" not in plan["order"])) and "copy" in ev:
+            st.wait_event(ev["copy"])
+        calls[stage](st.cuda_stream)
+        if stage not in ev:
+            ev[stage] = torch.cuda.Event()
+        ev[stage].record(st)
+    last = streams[plan["assign"][plan["order"][-1]][0]]
+    for stage in plan["order"]:
+        if streams[plan["assign"][stage][0]] is not last:
+            last.wait_event(ev[stage])
+    with torch.cuda.stream(last):
+        w["host_result"].copy_(w["result"], non_blocking=True)
+    if "copy" not in ev:
+        ev["copy"] = torch.cuda.Event()
+    ev["copy"].record(last)
+    return last
+
+
 def algorithmic_bytes(cfg, fused=False):
     """Per launch (= per step on one rank), SURVEY.md 8(d)."""
     n, A, V, M = cfg["n_chunks"], cfg["A"], cfg["V"], cfg["n_mels"]
@@ -702,6 +780,9 @@ def parse_args(argv=None):
                          "inputs are shared), so the 32-CU, latency-bound DTW of one step overlaps the other steps' kernels "
                          "with no cross-stream dependency at all.  The line also carries the single-batch-in-flight time; "
                          "per-stage times and the roofline always come from the single-stream pass")
+    ap.add_argument("--schedule", default="hilo", choices=sorted(SCHEDULES),
+                    help="how the stages of one batch share the chip when --pipeline > 1 (see SCHEDULES): serial = one stream per "
+                         "batch; hilo = per batch a high-priority stream (stft_mel, dtw_kernel) and a low-priority one (cost, log-prob)")
     ap.add_argument("--align", default="auto", choices=["auto", "split", "fused"],
                     help="split: wt_cost_batch then wt_dtw_batch (two timed stages, batched kernels only); fused: ONE "
                          "wt_align_batch_v3 (small units through the fused kernel; timed as the cost stage); auto = fused for "
@@ -712,7 +793,7 @@ def parse_args(argv=None):
                          "dtw: only the (32-CU, latency-bound) DTW runs beside the (HBM-bound) log-prob gather")
     # --- process plumbing (see orchestrate()): the measuring legs run in child processes of this script
     ap.add_argument("--role", default="orchestrate", choices=["orchestrate", "kernel", "cpu", "e2e"], help=argparse.SUPPRESS)
-    ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient"], help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient", "recordings"], help=argparse.SUPPRESS)
     ap.add_argument("--e2e-streams", type=int, default=32,
                     help="recordings per decoder op of the default-strategy leg (transcribe_batch; 32 = BASELINE configs[1])")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
@@ -809,6 +890,10 @@ def role_kernel(args):
                      **result_buffers(w["jumps"].numel(), w["logprob"].numel(), dev))
             pipe.append(c)
         pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
+    plan = SCHEDULES[args.schedule] if (args.pipeline > 1 and not dry and not args.graph) else None
+    if plan is not None and w.get("align") == "fused":
+        plan = dict(plan, order=[st_ for st_ in plan["order"] if st_ != "dtw"])      # (one entry point: cost + DTW as the cost stage)
+    plan_stream_sets = [plan_streams(dev, plan) for _ in range(args.pipeline)] if plan is not None else None
 
     rank_seconds = []            # N > 1: per timed region, every rank's own seconds (before the closing barrier)
     use_gather = [True]          # (switched off for the "what does the gather cost" regions at the end)
@@ -821,6 +906,12 @@ def role_kernel(args):
             return
         if pipelined:
             j = k % args.pipeline
+            if plan is not None:
+                last = run_step_plan(pipe[j], plan, plan_stream_sets[j])
+                if gatherers is not None and use_gather[0]:
+                    with torch.cuda.stream(last):
+                        gatherers[j].gather(pipe[j]["jumps"], pipe[j]["logprob"])
+                return
             with torch.cuda.stream(pipe_streams[j]):
                 run_step(pipe[j], ev, None)
                 if gatherers is not None and use_gather[0]:
@@ -979,9 +1070,11 @@ def role_kernel(args):
                                      "path enumeration and on transformers' DTW for tie-free inputs)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
+                       "schedule": (args.schedule if plan is not None and batches_in_flight > 1 else "serial"),
+                       "schedule_streams": ({k_: list(v_) for k_, v_ in plan["assign"].items()} if plan is not None and batches_in_flight > 1 else None),
                        "alignment_entry": "wt_align_batch_v3 (batched row pass + fused small-unit tail kernel; timed as the cost stage)"
                                           if w.get("align") == "fused" else "wt_cost_batch + wt_dtw_batch",
-                       "rccl_ranks_seen": ranks_seen,
+                       "rccl_ranks_seen": ranks_seen, "cpu_threads_per_rank": int(torch.get_num_threads()),
                        "result_gather": f"{'gloo (dry run)' if dry else 'rccl'} gather to rank 0, one message per {args.gather_every} steps"
                                         if gatherers is not None else "none"},
             "timing": {"regions": len(regions), "steps_per_region": args.steps, "statistic": "median region",
@@ -1045,45 +1138,97 @@ def role_cpu(args):
     emit(out)
 
 
+def ragged_window(rs, frames, ts0, eot, lo=40, hi=160):
+    """One window's scripted transcript with its OWN shape: 2-9 timestamped segments, 40-160 text tokens in all (scaled
+    down for a short window), segment lengths and pauses drawn at random inside `frames` 20 ms frames.  Text tokens are
+    `None` = "the model's most likely text token" (log-probabilities that mean something); the first timestamp respects
+    max_initial_timestamp (1 s), timestamps never decrease (the sampler's rules: a scripted token the filters suppress
+    would have log-probability -inf)."""
+    from golden import make_golden_transcribe as G
+    n_seg = int(rs.randint(2, 10))
+    total = int(rs.randint(lo, hi + 1) * min(1.0, frames / 1500.0 + 0.2))
+    total = max(total, n_seg)
+    share = rs.dirichlet(np.full(n_seg, 2.0))
+    usable = max(frames - 60, 10 * n_seg)
+    segs, t = [], int(rs.randint(0, min(50, max(1, frames // 10))))
+    for k in range(n_seg):
+        dur = max(6, int(share[k] * usable))
+        n_tok = max(3, int(round(share[k] * total)))
+        s0, e0 = t, min(t + dur, frames - 1)
+        if e0 - s0 < 4:
+            break
+        # (two scripted word pieces first: a segment whose most-likely tokens all happen to be punctuation has no words, and
+        #  the reference's state machine -- T.py:1002-1018 `reset(add_segment=False)` -- then loses the next segment's start)
+        segs.append((s0, G.text_ids(int(rs.randint(1 << 30)), 2) + [None] * (n_tok - 2), e0))
+        t = min(e0 + int(rs.randint(0, 12)), frames - 2)
+    return G.window_script(ts0, eot, segs, "eot")
+
+
+def words_of(r):
+    return [(w["text"], w["start"], w["end"], w["confidence"]) for s_ in r["segments"] for w in s_["words"]]
+
+
+def word_gaps(a, b, what):
+    """a, b: words_of() of two runs with RAW confidences (words.RAW_CONFIDENCE).  -> (max |dt|, max |dconfidence|,
+    max |d mean log-prob|): confidence = exp(mean log-prob of the word's tokens), so log(confidence) IS the mean."""
+    import math
+    assert [x[0] for x in a] == [x[0] for x in b], f"{what}: words differ"
+    dt = max([0.0] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
+    dc = max([0.0] + [abs(x[3] - y[3]) for x, y in zip(a, b)])
+    dl = 0.0
+    for x, y in zip(a, b):
+        assert (x[3] == 0) == (y[3] == 0), (what, x, y)
+        if x[3] and y[3]:
+            dl = max(dl, abs(math.log(x[3]) - math.log(y[3])))
+    return dt, dc, dl
+
+
 def run_efficient_leg(args, emit):
     """The DEFAULT strategy of transcribe() (the reference's efficient strategy: word alignment on the fly while the
-    backend decodes, T.py:359-1001) on 30 s synthetic clips with a scripted ~110-token transcript in 5 segments, whisper
-    double as the model:
-      1_stream        what a caller of the reference's API gets per process: transcribe(model, clip), one decoder stream,
-                      one token at a time through the backend's own Python loop;
-      B_streams       transcribe_batch(model, clips): B independent recordings stepping through the decoder together
-                      (whisper_timestamped/streams.py), B = --e2e-streams (32 = BASELINE configs[1]'s batch), and 4 B;
-      cpu_baseline    the reference-shaped CPU path for the same clips: the same model on the host cores, unfused
-                      attention with per-token QK capture, a second projection + logit filters per token, one
-                      synchronous alignment per segment through oracle/ (the reference's shape, T.py:783-793,849-881,
-                      544-557), one stream -- a bounded sample;
-      parity          every B-stream recording against the one-stream output (texts, word times, confidences) and the
-                      sampled clips against the CPU path's."""
+    backend decodes, T.py:359-1001), whisper double as the model:
+      1_stream          what a caller of the reference's API gets per process: transcribe(model, clip), one decoder stream,
+                        one token at a time through the backend's own Python loop;
+      B_streams         transcribe_batch(model, clips): B independent recordings stepping through the decoder together
+                        (whisper_timestamped/streams.py), B = --e2e-streams (32 = BASELINE configs[1]'s batch), and 4 B --
+                        UNIFORM work: 30 s clips, one scripted ~110-token transcript in 5 segments for every stream (every
+                        stream finishes in the same decoder call: the lock-step best case);
+      ragged_B_streams  the same on RAGGED work: clip lengths U[5, 30] s, a different scripted transcript per stream
+                        (2-9 segments, 40-160 tokens), with the driver's streams-per-loop histogram;
+      long_form_1h_islands  BASELINE configs[3] at N = 1, uniform and ragged (per-window transcripts drawn per island, so
+                        the prompts of windows 2, 3 differ in length from stream to stream under condition_on_previous_text);
+      cpu_baseline      the reference-shaped CPU path for the same clips: the same model on the host cores, unfused
+                        attention with per-token QK capture, a second projection + logit filters per token, one
+                        synchronous alignment per segment through oracle/ (the reference's shape, T.py:783-793,849-881,
+                        544-557), one stream -- a bounded sample;
+      parity            every B-stream recording against the one-stream output (word times, raw confidences, mean
+                        log-probabilities) and the sampled clips against the CPU path's."""
     import many_helper as H          # tests/: the whisper double as the model, the scripted transcript
     import whisper_double as W
     from whisper_double.decoding import Script, set_row_scripts, set_script
     from golden import make_golden_transcribe as G
     W.install()
     import whisper_timestamped as wt
-    from whisper_timestamped import streams
-    dev = "cuda:0"
+    from whisper_timestamped import streams, words
+    words.RAW_CONFIDENCE = True      # confidences before the reference's round(, 3): parity is asserted on the raw values
+    dev = getattr(args, "e2e_device", "cuda:0")     # (a CPU dry run of this leg's host logic: tools/dry_run_efficient_leg.py)
     model = H.load_base(dev)
     B = args.e2e_streams
+    TS0, EOT = 50364, 50257
     g = torch.Generator().manual_seed(7)
     clips = [(0.05 * torch.randn(30 * 16000, generator=g)).float() for _ in range(4)]
     segs = [(s, [None] * n, e) for s, n, e in H.SEGMENTS]
-    window = G.window_script(50364, 50257, segs, "eot")
-    out = {"workload": "whisper-base (random init, fp32), 30 s synthetic clips, scripted transcript of ~110 tokens in 5 "
-                       "timestamped segments, transcribe() with its defaults (efficient strategy, greedy)"}
-
-    def words_of(r):
-        return [(w["text"], w["start"], w["end"], w["confidence"]) for s_ in r["segments"] for w in s_["words"]]
+    window = G.window_script(TS0, EOT, segs, "eot")
+    out = {"workload": "whisper-base (random init, fp32), synthetic clips, scripted transcripts, transcribe() with its defaults "
+                       "(efficient strategy, greedy, condition_on_previous_text=True); uniform legs: 30 s clips, one ~110-token "
+                       "transcript in 5 timestamped segments for every stream; ragged legs: U[5, 30] s clips, 2-9 segments and "
+                       "40-160 tokens drawn per stream"}
+    bars = {"dt_word_s": 0.02, "dconfidence": 1e-4, "dmean_logprob": 2e-4}
 
     # ---- one stream (the reference's shape of the call)
-    def one(clip):
-        set_script(Script([window]))
+    def one(clip, windows=None, **kw):
+        set_script(Script(windows if windows is not None else [window]))
         try:
-            return wt.transcribe(model, clip, language="en", fp16=False)
+            return wt.transcribe(model, clip, language="en", fp16=False, **kw)
         finally:
             set_script(None)
     one(clips[0])                                           # warm-up: allocations, GEMM plans, the library's arenas
@@ -1099,8 +1244,8 @@ def run_efficient_leg(args, emit):
     emit(out)
 
     # ---- B streams per decoder op
-    def many(n):
-        scripts = [Script([window]) for _ in range(n)]
+    def batch_of(audios, window_lists, max_streams, **kw):
+        scripts = [Script(ws) for ws in window_lists]
 
         def on_group(idx):
             for i in idx:
@@ -1108,10 +1253,27 @@ def run_efficient_leg(args, emit):
             set_row_scripts([scripts[i] for i in idx])
         streams.ON_GROUP_DECODE = on_group
         try:
-            return wt.transcribe_batch(model, [clips[k % len(clips)] for k in range(n)], max_streams=n, language="en", fp16=False)
+            return wt.transcribe_batch(model, audios, max_streams=max_streams, language="en", fp16=False, **kw)
         finally:
             streams.ON_GROUP_DECODE = None
             set_row_scripts(None)
+
+    def many(n):
+        return batch_of([clips[k % len(clips)] for k in range(n)], [[window]] * n, n)
+
+    def histogram(sizes):
+        h = {}
+        for x in sizes:
+            h[int(x)] = h.get(int(x), 0) + 1
+        return {str(k): h[k] for k in sorted(h)}
+
+    def driver_stats():
+        d = dict(streams.LAST_RUN)
+        sizes = d.pop("streams_per_loop", [])
+        d["streams_per_loop_histogram"] = histogram(sizes)
+        d["mean_streams_per_loop"] = round(float(np.mean(sizes)), 2) if sizes else None
+        return d
+
     for n_streams in (B, 4 * B):
         many(n_streams)                                     # warm-up at the timed shape
         torch.cuda.synchronize()
@@ -1121,19 +1283,54 @@ def run_efficient_leg(args, emit):
             batch = many(n_streams)
         torch.cuda.synchronize()
         elB = (time.perf_counter() - t0) / reps
-        worst_t = worst_c = 0.0
+        worst = [0.0, 0.0, 0.0]
         for k, r in enumerate(batch):
-            a, b = words_of(r), words_of(singles[k % len(clips)])
-            assert [x[0] for x in a] == [x[0] for x in b], "B-stream and one-stream words differ"
-            worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
-            worst_c = max([worst_c] + [abs(x[3] - y[3]) for x, y in zip(a, b)])
+            worst = [max(x, y) for x, y in zip(worst, word_gaps(words_of(r), words_of(singles[k % len(clips)]), "B-stream vs one-stream"))]
         key = f"{n_streams}_streams"
         out[key] = {"audio_s_per_s": round(30.0 * n_streams / elB, 1), "clips": n_streams, "seconds": round(elB, 3),
                     "ms_per_clip": round(1e3 * elB / n_streams, 2), "words": sum(len(words_of(r)) for r in batch),
                     "speedup_vs_1_stream": round((30.0 * n_streams / elB) / (30.0 * len(clips) / el1), 2),
-                    "driver": dict(streams.LAST_RUN),
-                    "parity_vs_1_stream": {"max_abs_dt_word_s": round(worst_t, 4), "max_abs_dconfidence": round(worst_c, 6)}}
-        assert worst_t <= 0.02 + 1e-9 and worst_c <= 1e-3 + 1e-9, out[key]
+                    "driver": driver_stats(),
+                    "parity_vs_1_stream": {"max_abs_dt_word_s": round(worst[0], 4), "max_abs_dconfidence_before_rounding": float(f"{worst[1]:.3g}"),
+                                           "max_abs_dmean_logprob_per_word": float(f"{worst[2]:.3g}")}}
+        assert worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4, out[key]
+        emit(out)
+
+    # ---- the same on RAGGED work: clip lengths U[5, 30] s, a different transcript per stream
+    def ragged_jobs(n, seed):
+        rs = np.random.RandomState(seed)
+        audios, wins, secs = [], [], []
+        for k in range(n):
+            sec = float(rs.uniform(5.0, 30.0))
+            audios.append(clips[k % len(clips)][:int(sec * 16000)].clone())
+            wins.append([ragged_window(rs, int(sec * 50), TS0, EOT)])
+            secs.append(sec)
+        return audios, wins, secs
+    for n_streams in (B, 4 * B):
+        print(f"[bench] default strategy: ragged, {n_streams} streams", file=sys.stderr, flush=True)
+        audios, wins, secs = ragged_jobs(n_streams, 100 + n_streams)
+        batch_of(audios, wins, n_streams)                   # warm-up at the timed shape
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            batch = batch_of(audios, wins, n_streams)
+        torch.cuda.synchronize()
+        elR = (time.perf_counter() - t0) / reps
+        stats = driver_stats()
+        worst, checked = [0.0, 0.0, 0.0], 0
+        for k in range(0, n_streams, max(1, n_streams // 16)):          # 16 of the recordings, one stream at a time
+            worst = [max(x, y) for x, y in zip(worst, word_gaps(words_of(batch[k]), words_of(one(audios[k], wins[k])), "ragged B-stream vs one-stream"))]
+            checked += 1
+        key = f"ragged_{n_streams}_streams"
+        tok = [len(w_[0]) for w_ in wins]
+        out[key] = {"audio_s_per_s": round(sum(secs) / elR, 1), "clips": n_streams, "audio_seconds": round(sum(secs), 1),
+                    "clip_seconds": "U[5, 30]", "tokens_per_transcript": {"min": min(tok), "mean": round(float(np.mean(tok)), 1), "max": max(tok)},
+                    "seconds": round(elR, 3), "words": sum(len(words_of(r)) for r in batch), "driver": stats,
+                    "parity_vs_1_stream": {"recordings_compared": checked, "max_abs_dt_word_s": round(worst[0], 4),
+                                           "max_abs_dconfidence_before_rounding": float(f"{worst[1]:.3g}"),
+                                           "max_abs_dmean_logprob_per_word": float(f"{worst[2]:.3g}")}}
+        assert worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4, out[key]
         emit(out)
 
     # ---- BASELINE configs[3] at N = 1: ONE long recording (1 h), its speech islands given (the reference's vad=[...] form;
@@ -1141,22 +1338,18 @@ def run_efficient_leg(args, emit):
     #      ranks the same call deals the islands to the ranks first (sharding.transcribe_islands, no data-path collective).
     from whisper_timestamped.sharding import transcribe_islands
     pattern = (90, 30, 30, 60, 30, 60)                      # island lengths in seconds: one to three 30 s windows each
-    durations = [pattern[k % len(pattern)] for k in range(72)]          # 12 x 300 s = one hour
-    assert sum(durations) == 3600
-    hour = torch.cat([clips[k % len(clips)] for k in range(120)])
+    n_islands = getattr(args, "e2e_islands", 72)                         # 72: 12 x 300 s = one hour
+    durations = [pattern[k % len(pattern)] for k in range(n_islands)]
+    total_s = sum(durations)
+    assert total_s == 3600 or n_islands != 72
+    hour = torch.cat([clips[k % len(clips)] for k in range(total_s // 30)])
     islands, t = [], 0.0
     for d_ in durations:
         islands.append((t, t + d_))
         t += d_
-
-    def on_batch(indices):
-        scripts = [Script([window] * (durations[i] // 30)) for i in indices]
-
-        def on_group(rows):                              # rows: positions in the rank's list of islands
-            for r in rows:
-                scripts[r].begin_window()
-            set_row_scripts([scripts[r] for r in rows])
-        streams.ON_GROUP_DECODE = on_group
+    rs_h = np.random.RandomState(77)
+    ragged_island_windows = [[ragged_window(rs_h, 1500, TS0, EOT) for _ in range(d_ // 30)] for d_ in durations]
+    uniform_island_windows = [[window] * (d_ // 30) for d_ in durations]
     n_windows = sum(d_ // 30 for d_ in durations)
     out["long_form_1h_islands"] = {
         "islands": len(islands), "island_seconds": "30 / 60 / 90 (one to three windows each)", "windows": n_windows,
@@ -1166,8 +1359,19 @@ def run_efficient_leg(args, emit):
                 "the ranks first.  Streams share a decoder loop only when their prompts have the same LENGTH (the decoder has no "
                 "padding mask: padding would move the positions and change the result): with the reference's default "
                 "condition_on_previous_text=True the later windows of a recording form their own loops until the prompt "
-                "saturates at 223 tokens; without conditioning every round is one loop"}
-    for label, cond in (("condition_on_previous_text", True), ("no_condition", False)):
+                "saturates at 223 tokens -- `uniform` scripts one transcript for every window (equal prompt lengths at equal "
+                "window index: the best case), `ragged` draws every window's transcript (2-9 segments, 40-160 tokens) per island"}
+
+    def island_run(window_lists, cond, hold=0):
+        def on_batch(indices):
+            scripts = [Script(window_lists[i]) for i in indices]
+
+            def on_group(rows):                              # rows: positions in the rank's list of islands
+                for r in rows:
+                    scripts[r].begin_window()
+                set_row_scripts([scripts[r] for r in rows])
+            streams.ON_GROUP_DECODE = on_group
+        streams.HOLD_FOR_BUCKET = hold
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         try:
@@ -1175,15 +1379,43 @@ def run_efficient_leg(args, emit):
                                         condition_on_previous_text=cond)
         finally:
             streams.ON_GROUP_DECODE = None
+            streams.HOLD_FOR_BUCKET = 0
             set_row_scripts(None)
         torch.cuda.synchronize()
-        el_h = time.perf_counter() - t0
-        assert len(merged["segments"]) == 5 * n_windows, (len(merged["segments"]), n_windows)
+        return merged, time.perf_counter() - t0
+
+    def island_parity(merged, window_lists, cond, picks):
+        """`picks` islands: transcribe() of the island's crop, one stream, against the island's words in the merged result."""
+        worst = [0.0, 0.0, 0.0]
+        for i in picks:
+            s_, e_ = islands[i]
+            crop = hour[int(round(s_ * 16000)):int(round(e_ * 16000))]
+            alone = one(crop, window_lists[i], condition_on_previous_text=cond)
+            mine = [(w["text"], w["start"] - s_, w["end"] - s_, w["confidence"]) for seg in merged["segments"]
+                    if s_ - 1e-6 <= seg["start"] < e_ - 1e-6 for w in seg["words"]]
+            worst = [max(x, y) for x, y in zip(worst, word_gaps(mine, words_of(alone), f"island {i} vs transcribe(crop)"))]
+        assert worst[0] <= 0.02 + 1e-6 and worst[1] <= 1e-4 and worst[2] <= 2e-4, worst
+        return {"islands_compared_with_transcribe_of_the_crop": list(picks), "max_abs_dt_word_s": round(worst[0], 4),
+                "max_abs_dconfidence_before_rounding": float(f"{worst[1]:.3g}"), "max_abs_dmean_logprob_per_word": float(f"{worst[2]:.3g}")}
+
+    legs = [("condition_on_previous_text", uniform_island_windows, True, 0), ("no_condition", uniform_island_windows, False, 0),
+            ("ragged", ragged_island_windows, True, 0), ("ragged_bucket_admission", ragged_island_windows, True, 2),
+            ("ragged_no_condition", ragged_island_windows, False, 0)]
+    for label, window_lists, cond, hold in legs:
+        print(f"[bench] default strategy, long form: {label}", file=sys.stderr, flush=True)
+        merged, el_h = island_run(window_lists, cond, hold)
+        stats = driver_stats()
+        n_seg_expected = sum(sum(1 for t_ in w_[:-1] if t_ is not None and t_ >= TS0) // 2 for ws in window_lists for w_ in ws)
+        assert len(merged["segments"]) == n_seg_expected, (label, len(merged["segments"]), n_seg_expected)
         starts = [s_["start"] for s_ in merged["segments"]]
         assert starts == sorted(starts) and all(len(s_["words"]) > 0 for s_ in merged["segments"])
-        out["long_form_1h_islands"][label] = {"audio_s_per_s": round(3600.0 / el_h, 1), "seconds": round(el_h, 3),
-                                              "driver": dict(streams.LAST_RUN), "segments": len(merged["segments"]),
-                                              "words": sum(len(s_["words"]) for s_ in merged["segments"])}
+        rec = {"audio_s_per_s": round(total_s / el_h, 1), "seconds": round(el_h, 3), "driver": stats, "segments": len(merged["segments"]),
+               "words": sum(len(s_["words"]) for s_ in merged["segments"]), "condition_on_previous_text": cond}
+        if hold:
+            rec["hold_for_bucket"] = hold
+        if label in ("condition_on_previous_text", "ragged"):
+            rec["parity_vs_1_stream"] = island_parity(merged, window_lists, cond, [i for i in (0, 1, 3, 6, 12) if i < n_islands])
+        out["long_form_1h_islands"][label] = rec
         emit(out)
 
     # ---- the reference-shaped CPU path, same clips (bounded sample)
@@ -1198,7 +1430,7 @@ def run_efficient_leg(args, emit):
             efficient.DEFER_ALIGNMENT = False              # one synchronous alignment per segment (T.py:544-557)
             model_cpu = H.load_base("cpu")
             all_threads = torch.get_num_threads()
-            runs, worst_t = [], 0.0
+            runs, worst = [], [0.0, 0.0, 0.0]
             # token-by-token decoding is a chain of small GEMVs: all cores of the box are not the fastest setting, so
             # the baseline is taken at the better of two thread counts (both reported)
             for k, threads in enumerate((min(16, all_threads), all_threads)):
@@ -1211,27 +1443,151 @@ def run_efficient_leg(args, emit):
                     set_script(None)
                     torch.set_num_threads(all_threads)
                 runs.append({"threads": threads, "seconds_per_clip": round(time.perf_counter() - t0, 2)})
-                a, b = words_of(r), words_of(singles[k])
-                assert [x[0] for x in a] == [x[0] for x in b], "GPU and CPU words differ"
-                worst_t = max([worst_t] + [max(abs(x[1] - y[1]), abs(x[2] - y[2])) for x, y in zip(a, b)])
+                worst = [max(x, y) for x, y in zip(worst, word_gaps(words_of(r), words_of(singles[k]), "GPU vs CPU path"))]
                 if threads == all_threads:
                     break
+            # one RAGGED clip as well (its own transcript), at the faster thread count
             best = min(runs, key=lambda x: x["seconds_per_clip"])
-            done = len(runs)
+            audios, wins, _ = ragged_jobs(B, 100 + B)
+            torch.set_num_threads(best["threads"])
+            set_script(Script(wins[1]))
+            try:
+                r = wt.transcribe(model_cpu, audios[1], language="en", fp16=False)
+            finally:
+                set_script(None)
+                torch.set_num_threads(all_threads)
+            gpu_same = None
+            done = len(runs) + 1
         finally:
             patch.undo()
             for k, v in saved.items():
                 setattr(efficient, k, v)
+        gpu_same = one(audios[1], wins[1])
+        worst = [max(x, y) for x, y in zip(worst, word_gaps(words_of(gpu_same), words_of(r), "GPU vs CPU path, ragged clip"))]
         out["cpu_baseline"] = {"value": round(30.0 / best["seconds_per_clip"], 2), "unit": "audio-seconds/s", "cores": best["threads"],
                                "kind": "port", "runs": runs,
                                "sample": f"one 30 s clip per thread setting (the faster one is the baseline), one stream: the same "
                                          f"whisper-base on the CPU, unfused attention with per-token QK capture, second projection "
                                          f"+ logit filters per token, one alignment per segment through oracle/"}
-        out["parity_vs_cpu_reference_path"] = {"clips": done, "max_abs_dt_word_s": round(worst_t, 4)}
+        out["parity_vs_cpu_reference_path"] = {"clips": done, "max_abs_dt_word_s": round(worst[0], 4),
+                                               "max_abs_dconfidence_before_rounding": float(f"{worst[1]:.3g}"),
+                                               "max_abs_dmean_logprob_per_word": float(f"{worst[2]:.3g}"), "bars": bars}
+        assert worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4, out["parity_vs_cpu_reference_path"]
         out["speedup_vs_cpu"] = {k: round(out[k]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)
-                                 for k in ("1_stream", f"{B}_streams", f"{4 * B}_streams")}
+                                 for k in ("1_stream", f"{B}_streams", f"{4 * B}_streams", f"ragged_{B}_streams", f"ragged_{4 * B}_streams")}
         emit(out)
     return out
+
+
+def role_recordings(args):
+    """N > 1 only (BASELINE configs[3] / north_star's "long-audio segment batches shard across the GPUs of one node with RCCL
+    broadcast of weights and gather of word-timestamp results"): 32 ragged recordings PER RANK (weak scaling) through
+    sharding.transcribe_recordings -- recordings dealt to the ranks largest-first, no data-path collective, every rank steps
+    ITS recordings through the decoder together (streams=32), weights broadcast from rank 0, result dictionaries gathered
+    to rank 0.  One child process per rank, its own process group (the kernel leg's is gone by now).  --dry-run: gloo, the
+    oracle-backed kernel stand-ins, the tiny model, 2 recordings per rank -- the plumbing, not a number."""
+    emit = make_emitter(args.out)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dry = args.dry_run
+    import torch.distributed as dist
+    from datetime import timedelta
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533"))
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+        # under torch.distributed.run the launcher's agent hosts the store: a second group of the same job joins it as a
+        # client under its own key prefix (the kernel leg's group left its rendezvous keys behind)
+        store = dist.PrefixStore("wt_recordings", dist.TCPStore(addr, port, world, is_master=False, timeout=timedelta(seconds=300)))
+    else:
+        store = dist.TCPStore(addr, port + 1, world, is_master=(rank == 0), timeout=timedelta(seconds=300))
+    import many_helper as H
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    if dry:
+        import cpu_kernel_standin
+        from test_streams_host import install_streams_standin
+        patch = H._Patch()
+        cpu_kernel_standin.install(patch)
+        install_streams_standin(patch)
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+        model = H.load_tiny("cpu")
+        per_rank, n_streams = 2, 2
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=dev)
+        model = H.load_base(dev)
+        per_rank, n_streams = args.e2e_streams, args.e2e_streams
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams, words
+    from whisper_timestamped.sharding import transcribe_recordings
+    words.RAW_CONFIDENCE = True
+    if rank != 0:                                          # rank 0 holds the truth: the others start from garbage and receive it
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.add_(1.0)
+    TS0, EOT = 50364, 50257
+    g = torch.Generator().manual_seed(7)
+    clips = [(0.05 * torch.randn(30 * 16000, generator=g)).float() for _ in range(4)]
+    rs = np.random.RandomState(4242)
+    audios, wins, secs = [], [], []
+    for k in range(per_rank * world):                      # every rank builds the same list; a rank only decodes its own
+        sec = float(rs.uniform(5.0, 30.0 if not dry else 8.0))
+        audios.append(clips[k % len(clips)][:int(sec * 16000)].clone())
+        wins.append([ragged_window(rs, int(sec * 50), TS0, EOT, *((40, 160) if not dry else (8, 16)))])
+        secs.append(sec)
+
+    def on_batch(indices):
+        scripts = [Script(wins[i]) for i in indices]
+
+        def on_group(rows):
+            for r in rows:
+                scripts[r].begin_window()
+            set_row_scripts([scripts[r] for r in rows])
+        streams.ON_GROUP_DECODE = on_group
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    opts = dict(language="en", fp16=False)
+    try:
+        if not dry:                                        # warm-up: allocations, GEMM plans, the communicator
+            transcribe_recordings(model, audios, dist=dist, broadcast_weights=True, streams=n_streams, on_batch=on_batch, **opts)
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        res = transcribe_recordings(model, audios, dist=dist, broadcast_weights=dry, streams=n_streams, on_batch=on_batch, **opts)
+        sync()
+        mine = time.perf_counter() - t0
+        dist.barrier()
+        el = time.perf_counter() - t0
+    finally:
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    every = [None] * world
+    dist.all_gather_object(every, round(mine, 4))
+    if rank == 0:
+        assert len(res) == len(audios) and all(len(r["segments"]) > 0 for r in res)
+        worst = [0.0, 0.0, 0.0]
+        picks = sorted({0, len(audios) // 2, len(audios) - 1})
+        for k in picks:                                    # recordings other ranks decoded, against one stream here
+            set_script(Script(wins[k]))
+            try:
+                alone = wt.transcribe(model, audios[k], **opts)
+            finally:
+                set_script(None)
+            worst = [max(x, y) for x, y in zip(worst, word_gaps(words_of(res[k]), words_of(alone), f"recording {k} (another rank) vs one stream"))]
+        assert worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4, worst
+        emit({"what": "sharding.transcribe_recordings: ragged recordings (U[5, 30] s, own transcripts) dealt to the ranks, "
+                      f"{n_streams} decoder streams per rank, weights broadcast from rank 0 (every other rank started from "
+                      "perturbed weights), result dictionaries gathered to rank 0",
+              "ranks": world, "recordings": len(audios), "recordings_per_rank": per_rank, "audio_seconds": round(sum(secs), 1),
+              "seconds": round(el, 3), "audio_s_per_s": round(sum(secs) / el, 1), "scaling": "weak",
+              "per_rank_seconds": every, "backend": "gloo (dry run)" if dry else "rccl",
+              "parity_vs_1_stream_on_rank_0": {"recordings_compared": picks, "max_abs_dt_word_s": round(worst[0], 4),
+                                               "max_abs_dconfidence_before_rounding": float(f"{worst[1]:.3g}"),
+                                               "max_abs_dmean_logprob_per_word": float(f"{worst[2]:.3g}")}})
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def role_e2e(args):
@@ -1239,6 +1595,8 @@ def role_e2e(args):
     if args.inject_fault == "e2e_" + args.leg:
         emit({"marker": "about to abort"})
         os.abort()
+    if args.leg == "recordings":
+        return role_recordings(args)
     torch.cuda.set_device(0)
     if args.leg == "efficient":
         run_efficient_leg(args, emit)
@@ -1321,10 +1679,19 @@ def orchestrate(args):
             out, err = out2, err2
         out = out or {}
         out["kernel_leg_first_attempt"] = first
+    multi = None
+    if world > 1 and args.e2e != "off":
+        # BASELINE configs[3] on N GPUs: recordings across the ranks, decoder streams within a rank (every rank runs its child)
+        multi, merr = run_child("e2e", ["--leg", "recordings"], 600)
+        multi = multi or {}
+        if merr:
+            multi["error"] = merr
     if rank != 0:
         sys.exit(1 if err else 0)
     if world > 1 and out is not None:
         out["cpu_baseline"] = "N=1 line only"
+        if multi is not None:
+            out["transcribe_recordings"] = multi
     if out is None:
         out = {"metric": "audio-seconds aligned/sec (whole node), whisper-base 30s chunks", "value": None, "unit": "audio-seconds/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True}
@@ -1372,7 +1739,7 @@ def orchestrate(args):
             e2e.update(half)
             if e2:
                 e2e["fp16_legs_error"] = e2
-            eff, e3 = run_child("e2e", ["--leg", "efficient"], 300)
+            eff, e3 = run_child("e2e", ["--leg", "efficient"], 600)
             eff = eff or {}
             eff.pop("marker", None)
             if e3:
@@ -1406,8 +1773,20 @@ def orchestrate(args):
         sys.exit(1)
 
 
+def cap_threads_per_rank():
+    """N ranks on one host: each gets its share of the cores for torch's intra-op pool (and its children inherit it) --
+    eight ranks with every core each is what made the default-strategy CPU leg 12x slower at 128 threads than at 16."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        n = max(1, (os.cpu_count() or world) // world)
+        torch.set_num_threads(n)
+        os.environ["OMP_NUM_THREADS"] = str(n)
+    return torch.get_num_threads()
+
+
 def main():
     args = parse_args()
+    cap_threads_per_rank()
     if args.role == "orchestrate":
         return orchestrate(args)
     # children: stdout belongs to the parent's single JSON line -- everything libraries print goes to stderr

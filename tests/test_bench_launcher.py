@@ -37,6 +37,13 @@ def check_line(d, n):
         assert 0.0 <= d["result_gather"]["share_of_step"] < 1.0 and d["result_gather"]["ms_per_step_without_gather"] > 0
         assert d["cpu_baseline"] == "N=1 line only"
         assert "roofline" in d and d["roofline"]["bound"] == "hbm"
+        # each rank keeps to its share of the host's cores
+        assert d["config"]["cpu_threads_per_rank"] <= max(1, (os.cpu_count() or n) // n)
+        # BASELINE configs[3] on N ranks: recordings across the ranks, decoder streams within a rank, results gathered
+        tr = d["transcribe_recordings"]
+        assert "error" not in tr, tr
+        assert tr["ranks"] == n and len(tr["per_rank_seconds"]) == n and tr["recordings"] == 2 * n
+        assert tr["parity_vs_1_stream_on_rank_0"]["max_abs_dt_word_s"] <= 0.02
 
 
 def test_one_rank_prints_exactly_one_json_line():
@@ -66,6 +73,21 @@ def test_driver_form_torchrun_two_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     assert len(lines) == 1, lines
     check_line(json.loads(lines[0]), 2)
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_both_launch_forms():
+    """The node's shape: eight ranks (gloo here, RCCL on the MI355X node no round has had): one line, rccl_ranks_seen 8,
+    per_rank of length 8, the recordings leg gathered from 8 ranks -- self-launched and in the driver's torchrun form."""
+    p, lines = run([sys.executable, BENCH, "--gpus", "8", *FAST], timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    check_line(json.loads(lines[0]), 8)
+    p, lines = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                    "127.0.0.1", "--master-port", "29651", BENCH, "--gpus", "8", *FAST], timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, lines
+    check_line(json.loads(lines[0]), 8)
 
 
 def test_a_dead_kernel_leg_is_rerun_and_reported():

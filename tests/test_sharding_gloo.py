@@ -107,6 +107,16 @@ def test_two_rank_shard_and_gather(tmp_path):
     assert out.read_text().startswith("ok 23 units over 2 ranks")
 
 
+@pytest.mark.timeout(600)
+def test_eight_rank_shard_and_gather(tmp_path):
+    """The node's shape (8 ranks, one per MI355X), on gloo: weights broadcast, 23 units dealt to 8 ranks, every rank's
+    records gathered double-buffered and verified unit by unit on rank 0 (no 8-GPU node has been available
+    to any round: this is what can be proven without one)."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(8, _free_port(), str(out)), nprocs=8, join=True)
+    assert out.read_text().startswith("ok 23 units over 8 ranks")
+
+
 def test_partition_is_balanced_and_deterministic():
     sys.path.insert(0, os.path.join(ROOT, "whisper-timestamped_amd"))
     from whisper_timestamped.sharding import partition_units

@@ -72,25 +72,60 @@ def step_serial(c, order, st):
         c["host_result"].copy_(c["result"], non_blocking=True)
 
 
-def step_hilo(c, order, lo, hi):
-    """cost, log-prob on `lo`; log-mel, DTW on `hi` (the DTW after its cost)."""
+def step_plan(c, plan, streams):
+    """plan["assign"][stage] = (stream key, priority); the stages are ISSUED in plan["order"]; the DTW waits for its cost
+    stage's event, the result copy for every stream of the step."""
     calls = c.setdefault("_calls", bench._stage_calls(c))
-    ev = c.setdefault("_ev_cost", torch.cuda.Event())
-    ev2 = c.setdefault("_ev_dtw", torch.cuda.Event())
-    for stage in order:
-        if stage in ("cost", "logprob"):
-            calls[stage](lo.cuda_stream)
-            if stage == "cost":
-                ev.record(lo)
-        elif stage == "dtw":
-            hi.wait_event(ev)
-            calls[stage](hi.cuda_stream)
-            ev2.record(hi)
-        else:
-            calls[stage](hi.cuda_stream)
-    lo.wait_event(ev2)
-    with torch.cuda.stream(lo):
+    ev = c.setdefault("_ev", {})
+    used = []
+    for stage in plan["order"]:
+        st = streams[plan["assign"][stage][0]]
+        if stage == "dtw":
+            st.wait_event(ev["cost"])
+        # the buffer set's previous step: its DTW has read the cost matrix this step's cost stage overwrites, its result copy
+        # has read the record this step's DTW / log-prob gather overwrite (no-ops when both sit on the same stream)
+        if stage == "cost" and "dtw" in ev:
+            st.wait_event(ev["dtw"])
+        if stage in ("dtw", "logprob") and "copy" in ev:
+            st.wait_event(ev["copy"])
+        calls[stage](st.cuda_stream)
+        e = ev.get(stage)
+        if e is None:
+            e = ev[stage] = torch.cuda.Event()
+        e.record(st)
+        if st not in used:
+            used.append(st)
+    last = streams[plan["assign"][plan["order"][-1]][0]]
+    for stage in plan["order"]:
+        if streams[plan["assign"][stage][0]] is not last:
+            last.wait_event(ev[stage])
+    with torch.cuda.stream(last):
         c["host_result"].copy_(c["result"], non_blocking=True)
+    e = ev.get("copy")
+    if e is None:
+        e = ev["copy"] = torch.cuda.Event()
+    e.record(last)
+
+
+H, N, L = "hi", "normal", "lo"
+STD = ["logmel", "cost", "dtw", "logprob"]
+PLANS = {
+    "serial": dict(assign={s: ("a", N) for s in STD}, order=STD),
+    "hilo": dict(assign={"logmel": ("h", H), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+    "hilo_lpfirst": dict(assign={"logmel": ("h", H), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)},
+                         order=["logmel", "logprob", "cost", "dtw"]),
+    "dtw_only_hi": dict(assign={"logmel": ("l", L), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+    "dtw_only_hi_lm_last": dict(assign={"logmel": ("l", L), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)},
+                                order=["cost", "dtw", "logprob", "logmel"]),
+    "hilo3": dict(assign={"logmel": ("n", N), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+    "hilo_lp_own": dict(assign={"logmel": ("h", H), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l2", L)}, order=STD),
+    "h2": dict(assign={"logmel": ("h1", H), "dtw": ("h2", H), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+    "all4": dict(assign={"logmel": ("h1", H), "dtw": ("h2", H), "cost": ("l1", L), "logprob": ("l2", L)}, order=STD),
+    "hi_vs_normal": dict(assign={"logmel": ("h", H), "dtw": ("h", H), "cost": ("l", N), "logprob": ("l", N)}, order=STD),
+    "normal_vs_lo": dict(assign={"logmel": ("h", N), "dtw": ("h", N), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+    "two_streams_no_prio": dict(assign={"logmel": ("h", N), "dtw": ("h", N), "cost": ("l", N), "logprob": ("l", N)}, order=STD),
+    "lm_lo_dtw_hi_lp_own": dict(assign={"logmel": ("l2", L), "dtw": ("h", H), "cost": ("l", L), "logprob": ("l", L)}, order=STD),
+}
 
 
 def main():
@@ -106,7 +141,8 @@ def main():
     w = bench.make_workload(dev, bench.WORKLOADS[args.workload], seed=1234)
     w["align"] = "split"
     rc, p_lo, p_hi = priority_range()
-    results = {"priority_range": {"rc": rc, "least": p_lo, "greatest": p_hi}, "variants": []}
+    results = {"priority_range": {"rc": rc, "least": p_lo, "greatest": p_hi}, "variants": [],
+               "plans": {k: {"assign": {s_: list(v) for s_, v in p["assign"].items()}, "issue_order": p["order"]} for k, p in PLANS.items()}}
     print("priority range", rc, p_lo, p_hi, flush=True)
     sets = buffer_sets(w, dev, 4)
     # reference results: the plain schedule on buffer set 0
@@ -114,36 +150,25 @@ def main():
     torch.cuda.synchronize()
     ref = sets[0]["host_result"].clone()
 
-    variants = []
-    for P in (1, 2, 3, 4):
-        for order in ORDERS:
-            if P == 1 and order != "same":
-                continue
-            for prio in ("none", "hilo", "hilo_noprio", "dtw_hi"):
-                if prio != "none" and order not in ("same", "stagger_lp"):
-                    continue
-                variants.append((P, order, prio))
+    prio = {H: p_hi, N: 0, L: p_lo}
+    variants = [(P, name) for P in (1, 2, 3) for name in PLANS]
     if args.only:
         keep = set(args.only.split(","))
-        variants = [v for v in variants if f"{v[0]}:{v[1]}:{v[2]}" in keep]
-
-    for P, order, prio in variants:
-        if prio == "none":
-            streams = [(make_stream(dev),) for _ in range(P)]
-        elif prio == "hilo":
-            streams = [(make_stream(dev, p_lo), make_stream(dev, p_hi)) for _ in range(P)]
-        elif prio == "hilo_noprio":
-            streams = [(make_stream(dev), make_stream(dev)) for _ in range(P)]
-        else:   # dtw_hi: serial order per batch, but every batch's stream is created high priority for odd batches
-            streams = [(make_stream(dev, p_hi if j % 2 else p_lo),) for j in range(P)]
+        variants = [v for v in variants if f"{v[0]}:{v[1]}" in keep]
+    from whisper_timestamped import _lib
+    for P, name in variants:
+        plan = PLANS[name]
+        streams = []
+        for j in range(P):
+            d = {}
+            for stage, (key, pr) in plan["assign"].items():
+                if key not in d:
+                    d[key] = make_stream(dev, prio[pr])
+            streams.append(d)
 
         def step(k):
             j = k % P
-            c, o = sets[j], ORDERS[order][j]
-            if len(streams[j]) == 1:
-                step_serial(c, o, streams[j][0])
-            else:
-                step_hilo(c, o, streams[j][0], streams[j][1])
+            step_plan(sets[j], plan, streams[j])
         for k in range(3 * P):
             step(k)
         torch.cuda.synchronize()
@@ -156,15 +181,14 @@ def main():
                 step(k)
             torch.cuda.synchronize()
             regions.append((time.perf_counter() - t0) / args.steps * 1e3)
-        rec = {"batches_in_flight": P, "order": order, "priorities": prio, "ms_per_step_median": round(float(np.median(regions)), 4),
+        rec = {"batches_in_flight": P, "plan": name, "ms_per_step_median": round(float(np.median(regions)), 4),
                "ms_per_step_min": round(float(min(regions)), 4), "ms_per_step_max": round(float(max(regions)), 4),
-               "results_identical": bool(ok)}
+               "ms_per_step_p90": round(float(np.percentile(regions, 90)), 4), "results_identical": bool(ok)}
         print(json.dumps(rec), flush=True)
         results["variants"].append(rec)
-        from whisper_timestamped import _lib
-        for tup in streams:
-            for s in tup:
-                _lib.release_stream(s)
+        for d in streams:
+            for s_ in d.values():
+                _lib.release_stream(s_)
         del streams
     results["variants"].sort(key=lambda r: r["ms_per_step_median"])
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -165,13 +165,22 @@ __device__ __forceinline__ void head_sum_row(const QT *row0, int64_t head_stride
                 const uint2 r = qp[k];
                 w[2 * k] = r.x; w[2 * k + 1] = r.y;
             }
-            const bool odd = sh != 0;   // wave-uniform
+            // wave-uniform, and a BRANCH: a row that starts on an even element (every row of a (.., T, 1500) ring does)
+            // skips the funnel shift altogether -- as a select it was 32 of the 458 VALU instructions of a 24-wide head-row
+            // (profiles/r4q_sq_counters_largev3_fp16.txt: the kernel is VALU-bound)
+            if (__builtin_amdgcn_readfirstlane(sh) != 0) {
 #pragma unroll
-            for (int k = 0; k < (C + 8) / 2; ++k) {
-                const unsigned v = odd ? __builtin_amdgcn_alignbit(w[k + 1], w[k], 16) : w[k];
-                const __half2 h2 = *reinterpret_cast<const __half2 *>(&v);
-                const float2 f2v = __half22float2(h2);
-                x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
+                for (int k = 0; k < (C + 8) / 2; ++k) {
+                    const unsigned v = __builtin_amdgcn_alignbit(w[k + 1], w[k], 16);
+                    const float2 f2v = __half22float2(*reinterpret_cast<const __half2 *>(&v));
+                    x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (C + 8) / 2; ++k) {
+                    const float2 f2v = __half22float2(*reinterpret_cast<const __half2 *>(&w[k]));
+                    x[2 * k] = f2v.x; x[2 * k + 1] = f2v.y;
+                }
             }
         } else {
             float *xs = lds[buf];  // xs[4+f] = element f; xs[0..3], xs[4+F..7+F] = reflected halo
