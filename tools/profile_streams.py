@@ -21,6 +21,8 @@ W.install()
 import whisper_timestamped as wt  # noqa: E402
 from whisper_timestamped import streams  # noqa: E402
 
+if os.environ.get("WT_PAUSE_GC") == "0":       # A/B: the cyclic collector left on while the batch decodes
+    streams.PAUSE_GC = False
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 model = H.load_base("cuda:0")
 g = torch.Generator().manual_seed(7)

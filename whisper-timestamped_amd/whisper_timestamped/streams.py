@@ -66,6 +66,22 @@ LAST_RUN = {}
 # admitted meanwhile (first windows: equal prompts) or another held stream may join it.  Never two rounds in a row, and
 # never when that would leave the round empty.  Results do not depend on it (a window's result depends on its own prompt).
 HOLD_FOR_BUCKET = 0
+PAUSE_GC = True               # pause Python's cyclic garbage collector while a batch decodes (see _run_streams)
+
+
+class paused_gc:
+    """`with paused_gc():` -- the cyclic collector off for the block (when PAUSE_GC and it was on), back on afterwards."""
+
+    def __enter__(self):
+        import gc
+        self.was = PAUSE_GC and gc.isenabled()
+        if self.was:
+            gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
 FALLBACK_READS = {"argmax": 0, "argmax_over_later_timestamps": 0, "logprob_of_another_token": 0}
 
 
@@ -166,7 +182,7 @@ class StreamRings:
         self.sel = tuple(torch.tensor([x[k] for x in sel], dtype=torch.int32, device=dev) for k in range(3))
         self.n_sel = len(sel)
         self.qk = torch.zeros((n_streams, max(self.n_slots, 1), self.capacity, self.n_ctx), dtype=dtype, device=dev)
-        tk = tokenizer
+        tk = tokenizer if tokenizer is not None else backend.get_tokenizer(model, task="transcribe", language="en")
         self.slice_begin = int(tk.timestamp_begin)
         self.aux_tokens = [int(tk.eot)] + ([int(tk.no_timestamps)] if tk.no_timestamps is not None else [])
         self.digest = torch.zeros((n_streams, self.capacity, _lib.DIGEST_WORDS), dtype=torch.float32, device=dev)
@@ -179,6 +195,7 @@ class StreamRings:
     @staticmethod
     def bytes_per_stream(model, alignment_heads, hooked_blocks, dtype, sample_len, tokenizer):
         dims = model.dims
+        tokenizer = tokenizer if tokenizer is not None else backend.get_tokenizer(model, task="transcribe", language="en")
         calls = min(dims.n_text_ctx, int(sample_len or dims.n_text_ctx // 2) + 1)
         _, n_slots = layer_head_slots(head_pairs(alignment_heads), len(hooked_blocks), dims.n_text_head)
         item = 2 if dtype == torch.float16 else 4
@@ -790,8 +807,12 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     loop_sizes = []
     verify = efficient.REUSE_DECODER_LOGITS == "auto"
     fused_checked = False
+    # The driver's loops allocate a few thousand small ACYCLIC objects per stream and window (token lists, word dictionaries,
+    # views): reference counting frees them; the cyclic collector only re-scans the process's long-lived objects (the model's
+    # modules, torch's own tables) every few thousand allocations -- a tenth of a 256-stream loop's host time
+    # (profiles/r5d_streams_gc.txt).  Paused for the duration of the batch, restored (and run once) at its end.
     try:
-        with torch.no_grad():
+        with torch.no_grad(), paused_gc():
             while True:
                 admit()
                 for st in streams:                            # (recordings with nothing to decode: empty audio)

@@ -287,10 +287,11 @@ def transcribe_batch(model, audios, max_streams=32, **options):
     if a["seed"] is not None:
         torch.manual_seed(a["seed"])
         torch.cuda.manual_seed_all(a["seed"])
-    pairs = streams.transcribe_efficient_streams(plan["model"], audios, trust_whisper_timestamps=a["trust_whisper_timestamps"],
-                                                 max_streams=max_streams, **plan["alignment_options"],
-                                                 **plan["whisper_options"], **plan["other_options"])
-    return [_assemble(t, w, plan) for t, w in pairs]
+    with streams.paused_gc():          # (thousands of small acyclic objects per stream: reference counting frees them)
+        pairs = streams.transcribe_efficient_streams(plan["model"], audios, trust_whisper_timestamps=a["trust_whisper_timestamps"],
+                                                     max_streams=max_streams, **plan["alignment_options"],
+                                                     **plan["whisper_options"], **plan["other_options"])
+        return [_assemble(t, w, plan) for t, w in pairs]
 
 
 transcribe = transcribe_timestamped
