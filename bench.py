@@ -810,6 +810,13 @@ def parse_args(argv=None):
     return args
 
 
+def _json_scalar(o):
+    """numpy scalars that slipped into a result dictionary"""
+    if hasattr(o, "item"):
+        return o.item()
+    raise TypeError(f"Object of type {o.__class__.__name__} is not JSON serializable")
+
+
 def make_emitter(path):
     """Children publish their (partial) results by atomically rewriting one JSON file: whatever was measured before
     a GPU fault is still there for the parent."""
@@ -818,7 +825,7 @@ def make_emitter(path):
             return
         tmp = path + ".tmp"
         with open(tmp, "w") as f:
-            json.dump(obj, f)
+            json.dump(obj, f, default=_json_scalar)
         os.replace(tmp, path)
     return emit
 
@@ -1181,7 +1188,7 @@ def word_gaps(a, b, what):
         assert (x[3] == 0) == (y[3] == 0), (what, x, y)
         if x[3] and y[3]:
             dl = max(dl, abs(math.log(x[3]) - math.log(y[3])))
-    return [max([0.0] + dts), dc, dl, len(dts), sum(d > 0.02 + 1e-9 for d in dts)]
+    return [float(max([0.0] + dts)), float(dc), float(dl), len(dts), int(sum(d > 0.02 + 1e-9 for d in dts))]
 
 
 def merge_gaps(worst, new):
@@ -1790,7 +1797,7 @@ def orchestrate(args):
                 out["max_abs_dt_word_vs_ref_s"] = max(dts) if dts else None
             except Exception:                              # noqa: BLE001 -- a summary key must never cost the line
                 out["max_abs_dt_word_vs_ref_s"] = None
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out, default=_json_scalar), flush=True)
     if out.get("value") is None:
         sys.exit(1)
 
