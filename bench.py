@@ -454,6 +454,13 @@ SCHEDULES = {
                "order": STAGE_ORDER},
     "two_streams": {"assign": {"logmel": ("hi", "normal"), "dtw": ("hi", "normal"), "cost": ("lo", "normal"), "logprob": ("lo", "normal")},
                     "order": STAGE_ORDER},
+    # hilo with ONE low-priority stream for the HBM-bound kernels of ALL batches in flight (a key that starts with
+    # "shared" names the same stream in every batch): two bandwidth kernels never compete with each other, each runs at
+    # its solo speed with a compute-bound kernel of either batch beside it
+    "hilo_one_lo": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("shared_lo", "low"), "logprob": ("shared_lo", "low")},
+                    "order": STAGE_ORDER},
+    "hilo_one_lo_normal": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("shared_lo", "normal"), "logprob": ("shared_lo", "normal")},
+                           "order": STAGE_ORDER},
 }
 
 
@@ -476,12 +483,20 @@ def priority_stream(dev, priority):
     return torch.cuda.ExternalStream(st.value, device=dev)
 
 
-def plan_streams(dev, plan):
+def plan_streams(dev, plan, shared=None):
+    """One HIP stream per stream key of the plan; keys that start with "shared" are taken from (and added to) `shared`,
+    the dictionary the caller passes for every batch in flight."""
     prio = stream_priorities()
     out = {}
     for stage in plan["order"]:
         key, level = plan["assign"][stage]
-        if key not in out:
+        if key in out:
+            continue
+        if key.startswith("shared") and shared is not None:
+            if key not in shared:
+                shared[key] = priority_stream(dev, prio[level])
+            out[key] = shared[key]
+        else:
             out[key] = priority_stream(dev, prio[level])
     return out
 
@@ -780,9 +795,12 @@ def parse_args(argv=None):
                          "inputs are shared), so the 32-CU, latency-bound DTW of one step overlaps the other steps' kernels "
                          "with no cross-stream dependency at all.  The line also carries the single-batch-in-flight time; "
                          "per-stage times and the roofline always come from the single-stream pass")
-    ap.add_argument("--schedule", default="hilo", choices=sorted(SCHEDULES),
+    ap.add_argument("--schedule", default="auto", choices=sorted(SCHEDULES) + ["auto"],
                     help="how the stages of one batch share the chip when --pipeline > 1 (see SCHEDULES): serial = one stream per "
-                         "batch; hilo = per batch a high-priority stream (stft_mel, dtw_kernel) and a low-priority one (cost, log-prob)")
+                         "batch; hilo = per batch a high-priority stream (stft_mel, dtw_kernel) and a low-priority one (cost, log-prob); "
+                         "auto = hilo where the DTW leaves most of the chip idle (<= 128 units per step, split cost / DTW entries), "
+                         "serial for the 256-unit and the fused small-unit workloads (measured: profiles/r5f_bench_driver_command.json "
+                         "vs r4u_bench_final.json)")
     ap.add_argument("--align", default="auto", choices=["auto", "split", "fused"],
                     help="split: wt_cost_batch then wt_dtw_batch (two timed stages, batched kernels only); fused: ONE "
                          "wt_align_batch_v3 (small units through the fused kernel; timed as the cost stage); auto = fused for "
@@ -796,6 +814,10 @@ def parse_args(argv=None):
     ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient", "recordings"], help=argparse.SUPPRESS)
     ap.add_argument("--e2e-streams", type=int, default=32,
                     help="recordings per decoder op of the default-strategy leg (transcribe_batch; 32 = BASELINE configs[1])")
+    ap.add_argument("--e2e-worker-processes", type=int, default=0,
+                    help="default-strategy leg: worker processes of the ragged long-form sub-leg (0 / 1 = skip it, the default: "
+                         "measured once, profiles/r5h_*: 4 processes x 8 streams = 1.33x one process x 32 streams -- the "
+                         "processes' small kernels serialise on the one device)")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--secondary", action="store_true", help=argparse.SUPPRESS)     # a kernel leg of another BASELINE config
     ap.add_argument("--dry-run", action="store_true",
@@ -897,10 +919,14 @@ def role_kernel(args):
                      **result_buffers(w["jumps"].numel(), w["logprob"].numel(), dev))
             pipe.append(c)
         pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(args.pipeline)]
-    plan = SCHEDULES[args.schedule] if (args.pipeline > 1 and not dry and not args.graph) else None
+    schedule = args.schedule
+    if schedule == "auto":
+        schedule = "hilo" if (not dry and w.get("align") == "split" and len(w["descs"]) <= 128) else "serial"
+    plan = SCHEDULES[schedule] if (args.pipeline > 1 and not dry and not args.graph) else None
     if plan is not None and w.get("align") == "fused":
         plan = dict(plan, order=[st_ for st_ in plan["order"] if st_ != "dtw"])      # (one entry point: cost + DTW as the cost stage)
-    plan_stream_sets = [plan_streams(dev, plan) for _ in range(args.pipeline)] if plan is not None else None
+    shared_streams = {}
+    plan_stream_sets = [plan_streams(dev, plan, shared_streams) for _ in range(args.pipeline)] if plan is not None else None
 
     rank_seconds = []            # N > 1: per timed region, every rank's own seconds (before the closing barrier)
     use_gather = [True]          # (switched off for the "what does the gather cost" regions at the end)
@@ -1077,7 +1103,7 @@ def role_kernel(args):
                                      "path enumeration and on transformers' DTW for tie-free inputs)",
                        "streams": {"none": 1, "lanes": 3, "dtw": 2, "dtw_logmel": 2, "cumask": 3}[args.overlap],
                        "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
-                       "schedule": (args.schedule if plan is not None and batches_in_flight > 1 else "serial"),
+                       "schedule": (schedule if plan is not None and batches_in_flight > 1 else "serial"),
                        "schedule_streams": ({k_: list(v_) for k_, v_ in plan["assign"].items()} if plan is not None and batches_in_flight > 1 else None),
                        "alignment_entry": "wt_align_batch_v3 (batched row pass + fused small-unit tail kernel; timed as the cost stage)"
                                           if w.get("align") == "fused" else "wt_cost_batch + wt_dtw_batch",
@@ -1146,29 +1172,9 @@ def role_cpu(args):
 
 
 def ragged_window(rs, frames, ts0, eot, lo=40, hi=160):
-    """One window's scripted transcript with its OWN shape: 2-9 timestamped segments, 40-160 text tokens in all (scaled
-    down for a short window), segment lengths and pauses drawn at random inside `frames` 20 ms frames.  Text tokens are
-    `None` = "the model's most likely text token" (log-probabilities that mean something); the first timestamp respects
-    max_initial_timestamp (1 s), timestamps never decrease (the sampler's rules: a scripted token the filters suppress
-    would have log-probability -inf)."""
-    from golden import make_golden_transcribe as G
-    n_seg = int(rs.randint(2, 10))
-    total = int(rs.randint(lo, hi + 1) * min(1.0, frames / 1500.0 + 0.2))
-    total = max(total, n_seg)
-    share = rs.dirichlet(np.full(n_seg, 2.0))
-    usable = max(frames - 60, 10 * n_seg)
-    segs, t = [], int(rs.randint(0, min(50, max(1, frames // 10))))
-    for k in range(n_seg):
-        dur = max(6, int(share[k] * usable))
-        n_tok = max(3, int(round(share[k] * total)))
-        s0, e0 = t, min(t + dur, frames - 1)
-        if e0 - s0 < 4:
-            break
-        # (two scripted word pieces first: a segment whose most-likely tokens all happen to be punctuation has no words, and
-        #  the reference's state machine -- T.py:1002-1018 `reset(add_segment=False)` -- then loses the next segment's start)
-        segs.append((s0, G.text_ids(int(rs.randint(1 << 30)), 2) + [None] * (n_tok - 2), e0))
-        t = min(e0 + int(rs.randint(0, 12)), frames - 2)
-    return G.window_script(ts0, eot, segs, "eot")
+    """tests/many_helper.ragged_window (the scripts are also built inside worker processes)."""
+    import many_helper as H
+    return H.ragged_window(rs, frames, ts0, eot, lo, hi)
 
 
 def words_of(r):
@@ -1378,8 +1384,7 @@ def run_efficient_leg(args, emit):
     for d_ in durations:
         islands.append((t, t + d_))
         t += d_
-    rs_h = np.random.RandomState(77)
-    ragged_island_windows = [[ragged_window(rs_h, 1500, TS0, EOT) for _ in range(d_ // 30)] for d_ in durations]
+    ragged_island_windows = H.ragged_island_windows(durations, seed=77, ts0=TS0, eot=EOT)
     uniform_island_windows = [[window] * (d_ // 30) for d_ in durations]
     n_windows = sum(d_ // 30 for d_ in durations)
     out["long_form_1h_islands"] = {
@@ -1428,6 +1433,7 @@ def run_efficient_leg(args, emit):
         assert gaps_ok_between_batch_sizes(worst), worst
         return gaps_report(worst, {"islands_compared_with_transcribe_of_the_crop": list(picks)})
 
+    ragged_words_per_island = []
     legs = [("condition_on_previous_text", uniform_island_windows, True, 0), ("no_condition", uniform_island_windows, False, 0),
             ("ragged", ragged_island_windows, True, 0), ("ragged_bucket_admission", ragged_island_windows, True, 2),
             ("ragged_no_condition", ragged_island_windows, False, 0)]
@@ -1443,9 +1449,47 @@ def run_efficient_leg(args, emit):
                "words": sum(len(s_["words"]) for s_ in merged["segments"]), "condition_on_previous_text": cond}
         if hold:
             rec["hold_for_bucket"] = hold
+        if label == "ragged":                                   # (per island, for the worker-process leg below)
+            per = []
+            for s_, e_ in islands:
+                per.append([(w["text"], round(w["start"] - s_, 2), round(w["end"] - s_, 2)) for seg in merged["segments"]
+                            if s_ - 1e-6 <= seg["start"] < e_ - 1e-6 for w in seg["words"]])
+            ragged_words_per_island[:] = per
         if label in ("condition_on_previous_text", "ragged"):
             rec["parity_vs_1_stream"] = island_parity(merged, window_lists, cond, [i for i in (0, 1, 3, 6, 12) if i < n_islands])
         out["long_form_1h_islands"][label] = rec
+        emit(out)
+
+    # ---- what recovers the ragged loss on ONE GPU: processes.  A decoder loop is bound by its one Python thread whether it
+    #      carries 1 stream or 32, so W worker processes (own interpreter, own HIP queues, own copy of the 290 MB model) run W
+    #      loops side by side: the islands as independent recordings through sharding.transcribe_many(streams=B / W).  On N
+    #      GPUs the N ranks ARE such processes.  (Timed between the workers' common start and the last result; process
+    #      start-up and model load are reported beside it.)
+    if dev != "cpu" and getattr(args, "e2e_worker_processes", 0) > 1:
+        import functools
+        from whisper_timestamped.sharding import transcribe_many
+        W_ = int(getattr(args, "e2e_worker_processes", 0))
+        print(f"[bench] default strategy, long form: ragged, {W_} worker processes", file=sys.stderr, flush=True)
+        crops = [hour[int(round(s_ * 16000)):int(round(e_ * 16000))].clone() for s_, e_ in islands]
+        t0 = time.perf_counter()
+        try:
+            res_w, slowest = transcribe_many(H.load_base, crops, workers_per_gpu=W_, devices=[dev], warmup=True, return_timing=True,
+                                             streams=max(1, B // W_), language="en", fp16=False,
+                                             on_batch=functools.partial(H.script_ragged_islands, durations=tuple(durations), seed=77))
+            wall = time.perf_counter() - t0
+            ref, n_w, n_moved = ragged_words_per_island, 0, 0
+            for i, r in enumerate(res_w):                         # (8 streams per loop there, 32 here: batch-size rounding, see word_gaps)
+                mine = [(x[0], x[1], x[2]) for x in words_of(r)]
+                assert [x[0] for x in mine] == [x[0] for x in ref[i]], f"island {i}: words differ between one process and {W_}"
+                n_w += len(mine)
+                n_moved += sum(max(abs(a_[1] - b_[1]), abs(a_[2] - b_[2])) > 0.02 + 1e-9 for a_, b_ in zip(mine, ref[i]))
+            out["long_form_1h_islands"]["ragged_worker_processes"] = {
+                "worker_processes": W_, "streams_per_process": max(1, B // W_), "audio_s_per_s": round(total_s / slowest, 1),
+                "seconds": round(slowest, 3), "seconds_incl_process_start_and_model_load": round(wall, 2),
+                "words_compared_with_the_one_process_run": n_w, "words_beyond_0.02_s": int(n_moved),
+                "vs_one_process": round((total_s / slowest) / out["long_form_1h_islands"]["ragged"]["audio_s_per_s"], 2)}
+        except Exception as e:                                   # noqa: BLE001 -- an optional leg must not cost the others
+            out["long_form_1h_islands"]["ragged_worker_processes"] = {"error": repr(e)[:300]}
         emit(out)
 
     # ---- the reference-shaped CPU path, same clips (bounded sample)

@@ -84,3 +84,53 @@ def script_clip_cpu(index):
         cpu_kernel_standin.install(_Patch())
         _STANDIN = True
     script_clip(index)
+
+
+# ---- ragged scripted transcripts (bench.py's ragged legs; also built inside worker processes, hence here)
+def ragged_window(rs, frames, ts0, eot, lo=40, hi=160):
+    """One window's scripted transcript with its OWN shape: 2-9 timestamped segments, 40-160 text tokens in all (scaled
+    down for a short window), segment lengths and pauses drawn at random inside `frames` 20 ms frames.  Text tokens: two
+    scripted word pieces, then `None` = "the model's most likely text token" (log-probabilities that mean something); the
+    first timestamp respects max_initial_timestamp (1 s), timestamps never decrease (the sampler's rules: a scripted token
+    the filters suppress would have log-probability -inf)."""
+    import numpy as np
+    from golden import make_golden_transcribe as G
+    n_seg = int(rs.randint(2, 10))
+    total = int(rs.randint(lo, hi + 1) * min(1.0, frames / 1500.0 + 0.2))
+    total = max(total, n_seg)
+    share = rs.dirichlet(np.full(n_seg, 2.0))
+    usable = max(frames - 60, 10 * n_seg)
+    segs, t = [], int(rs.randint(0, min(50, max(1, frames // 10))))
+    for k in range(n_seg):
+        dur = max(6, int(share[k] * usable))
+        n_tok = max(3, int(round(share[k] * total)))
+        s0, e0 = t, min(t + dur, frames - 1)
+        if e0 - s0 < 4:
+            break
+        # (two scripted word pieces first: a segment whose most-likely tokens all happen to be punctuation has no words, and
+        #  the reference's state machine -- T.py:1002-1018 `reset(add_segment=False)` -- then loses the next segment's start)
+        segs.append((s0, G.text_ids(int(rs.randint(1 << 30)), 2) + [None] * (n_tok - 2), e0))
+        t = min(e0 + int(rs.randint(0, 12)), frames - 2)
+    return G.window_script(ts0, eot, segs, "eot")
+
+
+def ragged_island_windows(durations, seed=77, ts0=50364, eot=50257):
+    """Per island (duration in seconds, a multiple of 30) one ragged window script per 30 s window."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    return [[ragged_window(rs, 1500, ts0, eot) for _ in range(int(d) // 30)] for d in durations]
+
+
+def script_ragged_islands(indices, durations=(), seed=77):
+    """transcribe_many(streams=N, on_batch=functools.partial(script_ragged_islands, durations=...)): in a worker process,
+    the ragged scripts of ITS islands (`indices` = positions in the caller's list, in stream order)."""
+    from whisper_double.decoding import Script, set_row_scripts
+    from whisper_timestamped import streams
+    windows = ragged_island_windows(durations, seed)
+    scripts = [Script(windows[i]) for i in indices]
+
+    def on_group(rows):
+        for r in rows:
+            scripts[r].begin_window()
+        set_row_scripts([scripts[r] for r in rows])
+    streams.ON_GROUP_DECODE = on_group

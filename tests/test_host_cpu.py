@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.wt_version.restype = ctypes.c_int
-    assert L.wt_version() == _lib.ABI_VERSION == 4
+    assert L.wt_version() == _lib.ABI_VERSION == 5
 
 
 def test_dynamic_symbol_table_is_exactly_the_header():
@@ -234,6 +234,17 @@ def test_c_abi_argument_validation_without_a_gpu():
     assert L.wt_qk_rows_batch(*args(40, 64, 0)) == -1 and b"40 layers" in L.wt_last_error()
     assert L.wt_qk_rows_batch(*args(2, 64, 8)) == -1 and b"rows 8..18 of 16" in L.wt_last_error()
     assert L.wt_qk_rows_batch(*args(2, 32, 0)) == -3 and b"head_dim=32" in L.wt_last_error()
+    # wt_logprob_digest_streams(logits, row_stride, n_rows, V, token, token_dtype, token_stride, ring_index, ring_rows, ring_row,
+    #                           aux_tokens_host, n_aux, slice_begin, digest, slice, stream)
+    aux = (C.c_int32 * 4)(1, 2, 3, 4)
+    dg = lambda **kw: L.wt_logprob_digest_streams(*[kw.get(k, d) for k, d in (   # noqa: E731
+        ("logits", p), ("row_stride", 100), ("n_rows", 4), ("V", 100), ("token", p), ("token_dtype", 1), ("token_stride", 1),
+        ("ring_index", p), ("ring_rows", 8), ("ring_row", 0), ("aux", aux), ("n_aux", 2), ("slice_begin", 90), ("digest", p),
+        ("slice", p), ("stream", 0))])
+    assert dg(n_rows=0) == 0                                                           # no rows: nothing to do
+    for bad in (dict(row_stride=10), dict(ring_row=8), dict(ring_rows=0), dict(n_aux=5), dict(slice_begin=100),
+                dict(token_dtype=2), dict(ring_index=0), dict(digest=0), dict(token=0), dict(logits=0)):
+        assert dg(**bad) == -1 and b"wt_logprob_digest_streams" in L.wt_last_error(), bad
     assert L.wt_shutdown() == 0
 
 
