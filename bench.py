@@ -926,7 +926,15 @@ def role_kernel(args):
     if plan is not None and w.get("align") == "fused":
         plan = dict(plan, order=[st_ for st_ in plan["order"] if st_ != "dtw"])      # (one entry point: cost + DTW as the cost stage)
     shared_streams = {}
-    plan_stream_sets = [plan_streams(dev, plan, shared_streams) for _ in range(args.pipeline)] if plan is not None else None
+    schedule_note = None
+    plan_stream_sets = None
+    if plan is not None:
+        try:
+            plan_stream_sets = [plan_streams(dev, plan, shared_streams) for _ in range(args.pipeline)]
+        except Exception as e:                             # noqa: BLE001 -- a runtime without stream priorities: the round-4 schedule
+            schedule_note = f"{schedule} not available ({e!r}): serial"
+            print(f"[bench] {schedule_note}", file=sys.stderr, flush=True)
+            plan, schedule = None, "serial"
 
     rank_seconds = []            # N > 1: per timed region, every rank's own seconds (before the closing barrier)
     use_gather = [True]          # (switched off for the "what does the gather cost" regions at the end)
@@ -1105,6 +1113,7 @@ def role_kernel(args):
                        "hip_graph": bool(args.graph), "batches_in_flight": batches_in_flight,
                        "schedule": (schedule if plan is not None and batches_in_flight > 1 else "serial"),
                        "schedule_streams": ({k_: list(v_) for k_, v_ in plan["assign"].items()} if plan is not None and batches_in_flight > 1 else None),
+                       "schedule_note": schedule_note,
                        "alignment_entry": "wt_align_batch_v3 (batched row pass + fused small-unit tail kernel; timed as the cost stage)"
                                           if w.get("align") == "fused" else "wt_cost_batch + wt_dtw_batch",
                        "rccl_ranks_seen": ranks_seen, "cpu_threads_per_rank": int(torch.get_num_threads()),
@@ -1211,6 +1220,18 @@ NO_GAPS = [0.0, 0.0, 0.0, 0, 0]
 # confidences and mean log-probabilities for every word, times within 0.02 s for at least 99 % of the words; the count and
 # the worst gap are reported.
 MAX_SHARE_OF_WORDS_MOVED_BY_BATCH_ROUNDING = 0.01
+
+
+PARITY_FAILURES = []      # legs whose parity check did not hold: reported in the line (`parity_failures`), never hidden
+
+
+def parity_flag(ok, what, detail):
+    """A parity check of a transcribe()-level sub-leg: recorded, logged, and the leg goes on (an assert here would cost
+    every sub-leg behind it); the line carries every failure at its top level."""
+    if not ok:
+        PARITY_FAILURES.append({"leg": what, "detail": detail})
+        print(f"[bench] PARITY CHECK FAILED in {what}: {detail}", file=sys.stderr, flush=True)
+    return bool(ok)
 
 
 def gaps_report(worst, extra=None):
@@ -1332,7 +1353,7 @@ def run_efficient_leg(args, emit):
                     "ms_per_clip": round(1e3 * elB / n_streams, 2), "words": sum(len(words_of(r)) for r in batch),
                     "speedup_vs_1_stream": round((30.0 * n_streams / elB) / (30.0 * len(clips) / el1), 2),
                     "driver": driver_stats(), "parity_vs_1_stream": gaps_report(worst)}
-        assert gaps_ok_between_batch_sizes(worst), out[key]
+        out[key]["parity_vs_1_stream"]["ok"] = parity_flag(gaps_ok_between_batch_sizes(worst), key, out[key]["parity_vs_1_stream"])
         emit(out)
 
     # ---- the same on RAGGED work: clip lengths U[5, 30] s, a different transcript per stream
@@ -1367,7 +1388,7 @@ def run_efficient_leg(args, emit):
                     "clip_seconds": "U[5, 30]", "tokens_per_transcript": {"min": min(tok), "mean": round(float(np.mean(tok)), 1), "max": max(tok)},
                     "seconds": round(elR, 3), "words": sum(len(words_of(r)) for r in batch), "driver": stats,
                     "parity_vs_1_stream": gaps_report(worst, {"recordings_compared": checked})}
-        assert gaps_ok_between_batch_sizes(worst), out[key]
+        out[key]["parity_vs_1_stream"]["ok"] = parity_flag(gaps_ok_between_batch_sizes(worst), key, out[key]["parity_vs_1_stream"])
         emit(out)
 
     # ---- BASELINE configs[3] at N = 1: ONE long recording (1 h), its speech islands given (the reference's vad=[...] form;
@@ -1430,8 +1451,9 @@ def run_efficient_leg(args, emit):
             mine = [(w["text"], w["start"] - s_, w["end"] - s_, w["confidence"]) for seg in merged["segments"]
                     if s_ - 1e-6 <= seg["start"] < e_ - 1e-6 for w in seg["words"]]
             worst = merge_gaps(worst, word_gaps(mine, words_of(alone), f"island {i} vs transcribe(crop)"))
-        assert gaps_ok_between_batch_sizes(worst), worst
-        return gaps_report(worst, {"islands_compared_with_transcribe_of_the_crop": list(picks)})
+        rep = gaps_report(worst, {"islands_compared_with_transcribe_of_the_crop": list(picks)})
+        rep["ok"] = parity_flag(gaps_ok_between_batch_sizes(worst), "long_form_1h_islands", rep)
+        return rep
 
     ragged_words_per_island = []
     legs = [("condition_on_previous_text", uniform_island_windows, True, 0), ("no_condition", uniform_island_windows, False, 0),
@@ -1546,11 +1568,14 @@ def run_efficient_leg(args, emit):
         # (a ragged clip as well, reported on its own: the CPU's and the GPU's fp32 GEMMs round differently, and on a
         #  repeated token a random-init model's flat attention leaves the DTW near-ties -- see the note above word_gaps)
         out["parity_vs_cpu_reference_path"]["ragged_clip"] = gaps_report(ragged_gap, {"seconds": round(audios[1].numel() / 16000.0, 2)})
-        assert worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4, out["parity_vs_cpu_reference_path"]
-        assert ragged_gap[1] <= 1e-4 and ragged_gap[2] <= 2e-4, out["parity_vs_cpu_reference_path"]
+        out["parity_vs_cpu_reference_path"]["ok"] = parity_flag(
+            worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4 and ragged_gap[1] <= 1e-4 and ragged_gap[2] <= 2e-4,
+            "default_strategy vs the CPU reference path", out["parity_vs_cpu_reference_path"])
         out["speedup_vs_cpu"] = {k: round(out[k]["audio_s_per_s"] / out["cpu_baseline"]["value"], 1)
                                  for k in ("1_stream", f"{B}_streams", f"{4 * B}_streams", f"ragged_{B}_streams", f"ragged_{4 * B}_streams")}
         emit(out)
+    out["parity_failures"] = list(PARITY_FAILURES)           # [] = every parity check of this leg held
+    emit(out)
     return out
 
 
@@ -1651,8 +1676,8 @@ def role_recordings(args):
             finally:
                 set_script(None)
             worst = merge_gaps(worst, word_gaps(words_of(res[k]), words_of(alone), f"recording {k} (another rank) vs one stream"))
-        assert gaps_ok_between_batch_sizes(worst), worst
-        emit({"what": "sharding.transcribe_recordings: ragged recordings (U[5, 30] s, own transcripts) dealt to the ranks, "
+        parity_flag(gaps_ok_between_batch_sizes(worst), "transcribe_recordings", gaps_report(worst))
+        emit({"parity_failures": list(PARITY_FAILURES), "what": "sharding.transcribe_recordings: ragged recordings (U[5, 30] s, own transcripts) dealt to the ranks, "
                       f"{n_streams} decoder streams per rank, weights broadcast from rank 0 (every other rank started from "
                       "perturbed weights), result dictionaries gathered to rank 0",
               "ranks": world, "recordings": len(audios), "recordings_per_rank": per_rank, "audio_seconds": round(sum(secs), 1),
@@ -1818,6 +1843,7 @@ def orchestrate(args):
             if e3:
                 eff["error"] = e3
             e2e["default_strategy"] = eff
+            out["e2e_parity_failures"] = eff.get("parity_failures")
             # BASELINE configs[2]: whisper-small shapes through the same second pass (what the reference's beam-search
             # path re-runs, teacher forced: transcribe.py:1197-1262), 32 chunks per launch set
             small, e4 = run_child("e2e", ["--leg", "fp32", "--e2e-model", "small", "--no-cpu-baseline", "--e2e-steps", "3"], 300)
