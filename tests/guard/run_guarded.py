@@ -192,6 +192,40 @@ def case_logprob(mode):
         assert torch.allclose(out, want_r, rtol=0, atol=2e-5), (V, n, dtype)
 
 
+def case_digest(mode):
+    """wt_logprob_digest_streams: rows of every alignment (row stride n_q * V and V), int32 / strided int64 tokens, a subset
+    of the ring blocks in any order, with and without the timestamp slice; fenced rows, tokens, ring index and rings."""
+    from whisper_timestamped import _lib as L
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(15)
+    for V, n_q, slice_begin, i64 in [(51865, 3, 50364, True), (51866, 1, 50365, False), (1000, 2, 990, True), (37, 1, 30, False)]:
+        n_blocks, rows_cap, gsz = 5, 6, 3
+        outs = torch.randn((gsz, n_q, V), generator=g, device=dev) * 4
+        toks_full = torch.randint(0, V, (gsz, 4), generator=g, device=dev, dtype=torch.int64 if i64 else torch.int32)
+        ring_index = torch.tensor([4, 0, 2], dtype=torch.int32, device=dev)
+        aux = [V - 1, 0]
+        res = []
+        for fence in (False, True):
+            f = (lambda t: guarded(t, mode)) if fence else (lambda t: t.clone())
+            o, t, ri = f(outs), f(toks_full), f(ring_index)
+            digest = f(torch.zeros((n_blocks, rows_cap, L.DIGEST_WORDS), device=dev))
+            sl = f(torch.zeros((n_blocks, rows_cap, V - slice_begin), device=dev))
+            for step in (0, rows_cap - 1):
+                L.logprob_digest_streams(o[:, -1], t[:, -1], ri, digest, sl, step, aux, slice_begin)
+            L.logprob_digest_streams(o[:, -1], t[:, -1], ri, digest, None, 1, aux, slice_begin)
+            torch.cuda.synchronize()
+            res.append((digest.clone(), sl.clone()))
+        a, b = res[0][0], res[1][0]
+        # (the split of a row into head / 16-byte body / tail follows the row's address: the summation order, hence the last
+        #  bits of log-sum-exp, depend on the alignment -- as for wt_logprob_gather_batch; everything else is exact)
+        assert torch.allclose(a[..., :3], b[..., :3], rtol=0, atol=2e-5), (V, n_q)
+        assert torch.equal(a[..., 1], b[..., 1]) and torch.equal(a[..., 3:].view(torch.int32), b[..., 3:].view(torch.int32)), (V, n_q)
+        assert torch.equal(res[0][1], res[1][1]), (V, n_q)
+        want = L.logprob_gather(outs[:, -1], toks_full[:, -1].to(torch.int32))
+        assert torch.equal(res[0][0][ring_index.long(), 0, 0], want), (V, n_q)          # same rows, same alignment: same bits
+        assert torch.equal(res[1][1][ring_index.long(), rows_cap - 1], outs[:, -1, slice_begin:])
+
+
 def case_logmel(mode):
     """Whole and ragged chunks, lengths that are not multiples of 4 / 160, 80 and 128 mel bins, + the padding detector."""
     from whisper_timestamped import _lib as L
@@ -284,6 +318,7 @@ CASES = {
     "odd_units_f32_rows_per_class": lambda m: case_odd_units(m, torch.float32, flags=5),
     "odd_units_f16_rows_per_class": lambda m: case_odd_units(m, torch.float16, flags=5),
     "logprob": case_logprob,
+    "digest": case_digest,
     "logmel": case_logmel,
     "capture": case_capture,
 }

@@ -13,7 +13,7 @@ pytestmark = [pytest.mark.gpu,
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNNER = os.path.join(ROOT, "tests", "guard", "run_guarded.py")
-CASES = ["step_kfull", "step_kreal", "step_largev3_fp16", "odd_units_f32", "odd_units_f16", "odd_units_f32_batched_only", "odd_units_f16_batched_only", "odd_units_f32_rows_per_class", "odd_units_f16_rows_per_class", "logprob", "logmel", "capture"]
+CASES = ["step_kfull", "step_kreal", "step_largev3_fp16", "odd_units_f32", "odd_units_f16", "odd_units_f32_batched_only", "odd_units_f16_batched_only", "odd_units_f32_rows_per_class", "odd_units_f16_rows_per_class", "logprob", "digest", "logmel", "capture"]
 
 
 @pytest.mark.parametrize("mode", ["end", "start"])

@@ -66,3 +66,42 @@ def test_batches_in_flight_on_distinct_streams(n_sets, n_chunks, steps):
                 for name, want in ref.items():
                     assert torch.equal(w[name][:want.shape[0]], want), f"step {k}: buffer set {j2}: {name} differs from its single-stream reference"
                 assert torch.equal(w["host_result"], ref["result"].cpu())
+
+
+@pytest.mark.parametrize("schedule,n_sets", [("hilo", 2), ("hilo", 3), ("two_streams", 2), ("dtw_hi", 2), ("hilo_one_lo", 2)])
+def test_stream_priority_schedules_reproduce_the_single_stream_results(schedule, n_sets):
+    """bench.py --schedule (round 5): the stages of a batch on a high- and a low-priority HIP stream, the DTW behind its
+    cost stage by event, a buffer set's next step behind what still reads its buffers.  Buffer sets with their OWN inputs,
+    >= 120 steps: every set equals its single-stream reference bit for bit at every checkpoint -- a missing cross-stream
+    dependency (the DTW reading a cost matrix that is being rewritten, a result record copied before the DTW has written
+    it) shows up as a difference."""
+    import bench
+    dev = torch.device("cuda", 0)
+    sets = [_set(bench, dev, 700 + j, 32) for j in range(n_sets)]
+    refs = []
+    for w in sets:
+        bench.run_step(w)
+        torch.cuda.synchronize()
+        refs.append(_snapshot(w))
+    plan = bench.SCHEDULES[schedule]
+    shared = {}
+    stream_sets = [bench.plan_streams(dev, plan, shared) for _ in range(n_sets)]
+    for w in sets:
+        for k in ("result", "mel", "cost"):
+            w[k].zero_()
+        w["host_result"].zero_()
+    torch.cuda.synchronize()
+    steps = 120
+    for k in range(steps):
+        j = k % n_sets
+        bench.run_step_plan(sets[j], plan, stream_sets[j])
+        if k % 40 == 39 or k == steps - 1:
+            torch.cuda.synchronize()
+            for j2, (w, ref) in enumerate(zip(sets, refs)):
+                for name, want in ref.items():
+                    assert torch.equal(w[name][:want.shape[0]], want), f"{schedule}, step {k}: buffer set {j2}: {name} differs"
+                assert torch.equal(w["host_result"], ref["result"].cpu()), f"{schedule}, step {k}: buffer set {j2}: host record differs"
+    from whisper_timestamped import _lib
+    for d in stream_sets:
+        for s in d.values():
+            _lib.release_stream(s)
