@@ -454,6 +454,12 @@ SCHEDULES = {
                "order": STAGE_ORDER},
     "two_streams": {"assign": {"logmel": ("hi", "normal"), "dtw": ("hi", "normal"), "cost": ("lo", "normal"), "logprob": ("lo", "normal")},
                     "order": STAGE_ORDER},
+    # hilo with other ISSUE orders (the assignment is the same): the cost stage's row pass needs 49 KB of LDS per workgroup,
+    # the persistent stft_mel launch fills every CU's LDS when it gets there first
+    "hilo_cost_first": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo", "low")},
+                        "order": ["cost", "logmel", "dtw", "logprob"]},
+    "hilo_logmel_last": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo", "low")},
+                         "order": ["cost", "dtw", "logprob", "logmel"]},
     # hilo with ONE low-priority stream for the HBM-bound kernels of ALL batches in flight (a key that starts with
     # "shared" names the same stream in every batch): two bandwidth kernels never compete with each other, each runs at
     # its solo speed with a compute-bound kernel of either batch beside it
