@@ -1786,7 +1786,7 @@ def orchestrate(args):
     multi = None
     if world > 1 and args.e2e != "off":
         # BASELINE configs[3] on N GPUs: recordings across the ranks, decoder streams within a rank (every rank runs its child)
-        multi, merr = run_child("e2e", ["--leg", "recordings"], 600)
+        multi, merr = run_child("e2e", ["--leg", "recordings"], 300)
         multi = multi or {}
         if merr:
             multi["error"] = merr
