@@ -311,3 +311,22 @@ def test_small_unit_mirror_matches_the_header(tmp_path):
         small += want
     assert n > 20000 and 0 < small < n
     assert _lib.small_unit(11, 144) and _lib.small_unit(64, 256) and not _lib.small_unit(224, 1500)
+
+
+def test_rounding_helpers_equal_the_builtin_round_on_numpy_scalars():
+    """words.round_timestamp / round_confidence: for numpy.float64 inputs the fast path must be bit-identical to
+    round(numpy.float64, n) -- numpy's multiply / rint / divide -- including ties, negatives, the sign of zero, inf, nan;
+    Python floats keep the builtin (correctly rounded) result, as in the reference (transcribe.py:1807-1811)."""
+    from whisper_timestamped import words
+    rng = np.random.RandomState(1)
+    vals = np.concatenate([rng.rand(60000) * 3700, rng.rand(20000), np.round(rng.rand(40000) * 100, 3) + 0.005, -rng.rand(10000) * 10,
+                           np.arange(0, 40, 0.005), np.array([0.0, -0.0, 1e-9, -1e-9, 1e15, 2.675, 1.005, 0.125, 0.375, np.inf, -np.inf, np.nan])])
+    for x in vals:
+        x = np.float64(x)
+        for fn, nd in ((words.round_timestamp, 2), (words.round_confidence, 3)):
+            a, b = round(x, nd), fn(x)
+            assert type(b) is np.float64
+            assert (a == b and np.signbit(a) == np.signbit(b)) or (np.isnan(a) and np.isnan(b)), (x, nd, a, b)
+    for x in (2.675, 1.005, 0.125, 12.3456, -0.0049):            # Python floats: the builtin
+        assert words.round_timestamp(x) == round(x, 2) and type(words.round_timestamp(x)) is float
+        assert words.round_confidence(x) == round(x, 3)
