@@ -59,8 +59,6 @@ N_SAMPLES = 30 * SAMPLE_RATE
 # loop, in row order, right before it starts
 ON_GROUP_DECODE = None
 LAST_RUN = {}
-# how often a stream's session asked for something other than the sampled token's log-probability (the reference's
-# fallbacks for a stuck decoder): tests / diagnostics
 # Bucket admission (0 / 1 = off): streams share a decoder loop only when their prompts have the same LENGTH.  A stream
 # whose length fewer than HOLD_FOR_BUCKET streams share this round may sit ONE round out -- next round the recordings
 # admitted meanwhile (first windows: equal prompts) or another held stream may join it.  Never two rounds in a row, and
@@ -82,6 +80,10 @@ class paused_gc:
         if self.was:
             import gc
             gc.enable()
+
+
+# how often a stream's session asked for something other than the sampled token's log-probability (the reference's
+# fallbacks for a stuck decoder): tests / diagnostics
 FALLBACK_READS = {"argmax": 0, "argmax_over_later_timestamps": 0, "logprob_of_another_token": 0}
 
 
