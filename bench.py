@@ -1150,6 +1150,15 @@ def role_kernel(args):
     if rank == 0:
         emit(line(single_regions, single_regions, 1))     # published before the multi-stream pass starts
     mark = len(rank_seconds)
+    if args.pipeline > 1 and not dry:
+        # the parity check above kept the GPU idle for seconds (the oracle runs on the host): the --warmup steps again, on the
+        # pipelined path, before its regions are timed
+        for k in range(max(args.warmup, 2 * args.pipeline)):
+            full_step(None, k, pipelined=True)
+        if gatherers is not None:
+            for g_ in gatherers:
+                g_.drain()
+        sync()
     regions = measure(True) if args.pipeline > 1 else single_regions
     check_results(pipe)
     if dist is not None and world > 1:
