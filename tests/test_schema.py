@@ -106,3 +106,17 @@ def test_gpu_results_validate_against_reference_schema():
         result = wt.transcribe(model, audio, fp16=False, sample_len=24, **opts)
         plain = _check(result, schema)
         assert len(plain["segments"]) > 0
+
+
+def test_bench_schedules_are_well_formed():
+    """bench.SCHEDULES: every stage of the step has a stream and a priority level, every stage is issued exactly once, and
+    the DTW is issued after the cost stage it waits for (run_step_plan waits on an event recorded at issue time)."""
+    import bench
+    for name, plan in bench.SCHEDULES.items():
+        if plan is None:
+            continue
+        assert sorted(plan["order"]) == sorted(bench.STAGE_ORDER), name
+        assert set(plan["assign"]) == set(bench.STAGE_ORDER), name
+        assert plan["order"].index("cost") < plan["order"].index("dtw"), name
+        for stage, (key, level) in plan["assign"].items():
+            assert isinstance(key, str) and level in ("low", "normal", "high"), (name, stage)
