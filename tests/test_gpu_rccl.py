@@ -244,4 +244,8 @@ def test_bench_two_gpus_prints_one_line_with_two_rccl_ranks():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert len(d["per_rank"]["ms_per_step"]) == 2 and "share_of_step" in d["result_gather"]
     assert d["parity_in_leg"]["ok"] and d["cpu_baseline"] == "N=1 line only" and d["roofline"]["frac"] > 0
+    # round 5: BASELINE configs[3] on N ranks -- recordings across the ranks, decoder streams within a rank, over RCCL
+    tr = d["transcribe_recordings"]
+    assert "error" not in tr, tr
+    assert tr["ranks"] == 2 and tr["backend"] == "rccl" and len(tr["per_rank_seconds"]) == 2 and tr["parity_failures"] == []
     _keep(d, "bench_two_gpus.json")
