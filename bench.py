@@ -454,11 +454,6 @@ SCHEDULES = {
                "order": STAGE_ORDER},
     "two_streams": {"assign": {"logmel": ("hi", "normal"), "dtw": ("hi", "normal"), "cost": ("lo", "normal"), "logprob": ("lo", "normal")},
                     "order": STAGE_ORDER},
-    # cost and log-prob gather do not depend on each other: on streams of their own they also overlap WITHIN a batch
-    "hilo_lp_own": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo2", "low")},
-                    "order": STAGE_ORDER},
-    "prio3": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("mid", "normal"), "logprob": ("lo", "low")},
-              "order": STAGE_ORDER},
     # hilo with other ISSUE orders (the assignment is the same): the cost stage's row pass needs 49 KB of LDS per workgroup,
     # the persistent stft_mel launch fills every CU's LDS when it gets there first
     "hilo_cost_first": {"assign": {"logmel": ("hi", "high"), "dtw": ("hi", "high"), "cost": ("lo", "low"), "logprob": ("lo", "low")},
