@@ -110,3 +110,55 @@ def test_logprob_digest_streams_kernel_against_the_full_rows():
     for step in range(n_steps):
         lp = _lib.logprob_gather(full[step].cuda(), sampled[step].to(torch.int32).cuda()).cpu().numpy()
         assert (lp == host[:, step, 0]).all(), (step, lp, host[:, step, 0])
+
+
+def test_thirty_two_ragged_streams_against_one_stream_each():
+    """What bench.py's `ragged_32_streams` leg asserts, as a test: 32 recordings of 5-30 s with transcripts of their own
+    (2-9 segments, 40-160 tokens, whisper-base shapes) through ONE decoder loop, every fourth one also through
+    transcribe() alone -- same words, confidences within 1e-4, mean log-probabilities within 2e-4, word times within
+    0.02 s for at least 99 % of the words (a batch of 32 and a batch of 1 round differently inside the backend's GEMMs;
+    a random-init model's flat attention turns that into a moved boundary where the script repeats a token: DESIGN.md 4)."""
+    import numpy as np
+    import bench
+    import many_helper as H
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams, words
+    model = H.load_base("cuda:0")
+    TS0, EOT = 50364, 50257
+    g = torch.Generator().manual_seed(7)
+    clips = [(0.05 * torch.randn(30 * 16000, generator=g)).float() for _ in range(4)]
+    rs = np.random.RandomState(132)
+    audios, wins = [], []
+    for k in range(32):
+        sec = float(rs.uniform(5.0, 30.0))
+        audios.append(clips[k % 4][:int(sec * 16000)].clone())
+        wins.append([H.ragged_window(rs, int(sec * 50), TS0, EOT)])
+    scripts = [Script(w_) for w_ in wins]
+
+    def on_group(idx):
+        for i in idx:
+            scripts[i].begin_window()
+        set_row_scripts([scripts[i] for i in idx])
+    words.RAW_CONFIDENCE = True
+    streams.ON_GROUP_DECODE = on_group
+    try:
+        batch = wt.transcribe_batch(model, audios, max_streams=32, language="en", fp16=False)
+        assert streams.LAST_RUN["decoder_loops"] == 1 and streams.LAST_RUN["streams_per_loop"] == [32]
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+        worst = bench.NO_GAPS
+        for k in range(0, 32, 4):
+            set_script(Script(wins[k]))
+            try:
+                alone = wt.transcribe(model, audios[k], language="en", fp16=False)
+            finally:
+                set_script(None)
+            worst = bench.merge_gaps(worst, bench.word_gaps(bench.words_of(batch[k]), bench.words_of(alone), f"recording {k}"))
+    finally:
+        words.RAW_CONFIDENCE = False
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    assert worst[3] > 150 and bench.gaps_ok_between_batch_sizes(worst), bench.gaps_report(worst)
