@@ -120,3 +120,30 @@ def test_bench_schedules_are_well_formed():
         assert plan["order"].index("cost") < plan["order"].index("dtw"), name
         for stage, (key, level) in plan["assign"].items():
             assert isinstance(key, str) and level in ("low", "normal", "high"), (name, stage)
+
+
+def test_bench_word_gap_bookkeeping():
+    """bench.word_gaps / merge_gaps / gaps_ok_between_batch_sizes: the per-word parity rule of the transcribe()-level legs
+    (texts equal, confidences within 1e-4, mean log-probabilities within 2e-4, times within 0.02 s for >= 99 % of the words)."""
+    import math
+    import bench
+    a = [("w%d" % i, 0.5 * i, 0.5 * i + 0.4, 0.01 * (1 + i % 7)) for i in range(300)]
+    same = bench.word_gaps(a, list(a), "same")
+    assert same == [0.0, 0.0, 0.0, 300, 0] and bench.gaps_ok_between_batch_sizes(same)
+    b = list(a)
+    b[10] = (a[10][0], a[10][1] + 0.22, a[10][2], a[10][3] * math.exp(1e-5))
+    g = bench.word_gaps(a, b, "one word moved")
+    assert abs(g[0] - 0.22) < 1e-12 and g[3:] == [300, 1] and 0 < g[2] < 2e-5
+    assert bench.gaps_ok_between_batch_sizes(g)                                   # 1 of 300 <= 1 %
+    for k in (20, 30, 40, 50):
+        b[k] = (a[k][0], a[k][1], a[k][2] + 0.04, a[k][3])
+    g = bench.word_gaps(a, b, "five words moved")
+    assert g[4] == 5 and not bench.gaps_ok_between_batch_sizes(g)                 # 5 of 300 > 1 %
+    c = list(a)
+    c[3] = (a[3][0], a[3][1], a[3][2], a[3][3] + 2e-4)
+    assert not bench.gaps_ok_between_batch_sizes(bench.word_gaps(a, c, "confidence off"))
+    m = bench.merge_gaps(same, g)
+    assert m[3] == 600 and m[4] == 5 and bench.gaps_report(m)["words_beyond_0.02_s"] == 5
+    import pytest
+    with pytest.raises(AssertionError):
+        bench.word_gaps(a, [("x",) + t[1:] for t in a], "texts differ")
