@@ -107,3 +107,32 @@ def test_cli_streams_writes_the_same_files_as_one_after_the_other(tmp_path, monk
                 assert all(abs(x["confidence"] - y["confidence"]) <= 1e-3 + 1e-9 for x, y in zip(sa["words"], sb["words"]))
         else:
             assert a == b, n
+
+
+def test_cli_streams_verbose_without_output_dir_still_prints_the_results(tmp_path, monkeypatch, capsys):
+    """--streams N --verbose True without --output_dir: the B-stream path prints no segments while it decodes,
+    so its results are dumped as JSON whatever --verbose says -- one document per recording, as in the non-verbose form."""
+    from test_streams_host import install_streams_standin
+    C = _patch(monkeypatch)
+    install_streams_standin(monkeypatch)
+    wavs = []
+    for k, seconds in enumerate((2.0, 3.0)):
+        w = tmp_path / f"clip{k}.wav"
+        _wav(str(w), seconds=seconds, seed=10 + k)
+        wavs.append(str(w))
+    common = ["--model", "tiny", "--device", "cpu", "--language", "en", "--fp16", "False", "--efficient"]
+    C.cli([*wavs, "--streams", "2", "--verbose", "True", *common])
+    verbose_out = capsys.readouterr().out
+    C.cli([*wavs, "--streams", "2", *common])
+    quiet_out = capsys.readouterr().out
+    assert verbose_out.count('"segments"') == 2 and quiet_out.count('"segments"') == 2
+    dec = json.JSONDecoder()
+    docs, pos = [], verbose_out.index("{")
+    while pos < len(verbose_out):
+        obj, end = dec.raw_decode(verbose_out, pos)
+        docs.append(obj)
+        nxt = verbose_out.find("{", end)
+        if nxt < 0:
+            break
+        pos = nxt
+    assert len(docs) == 2 and all("segments" in d_ and "text" in d_ for d_ in docs)
