@@ -518,3 +518,30 @@ def test_vectorized_timestamp_rules_are_kept_only_when_they_reproduce_the_backen
     task = type("T", (), {"logit_filters": [old]})()
     assert streams.vectorize_filters(task).logit_filters[0] is old
     streams._RULES_PROBED.clear()
+
+
+def test_fallback_paths_of_transcribe_batch_reuse_the_model_the_plan_loaded(monkeypatch):
+    """ADVICE r4: with `model` given as a NAME, transcribe_batch's one-by-one fallbacks (calls the B-stream path cannot take;
+    a backend without DecodingTask._main_loop) must decode every recording with the model _plan has already loaded -- not
+    load it again per recording."""
+    import whisper_double as W
+    W.install()
+    import importlib
+    import whisper_timestamped as wt
+    T = importlib.import_module("whisper_timestamped.transcribe")          # (the package re-exports the FUNCTION under this name)
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    model = W.build_model("tiny", seed=0, device="cpu")
+    loads = []
+    monkeypatch.setattr(T, "load_model", lambda name, *a, **k: (loads.append(name), model)[1])
+    g = torch.Generator().manual_seed(1)
+    audios = [(0.05 * torch.randn(16000 * 3, generator=g)).float() for _ in range(3)]
+    # (a) beam search: not batchable -> one recording at a time
+    out = wt.transcribe_batch("tiny", audios, language="en", fp16=False, beam_size=2, sample_len=6)
+    assert len(out) == 3 and loads == ["tiny"], loads
+    # (b) a backend that lacks the decoder loop as a method
+    loads.clear()
+    from whisper_timestamped import streams
+    monkeypatch.setattr(streams, "backend_missing", lambda: ["DecodingTask._main_loop"])
+    out = wt.transcribe_batch("tiny", audios, language="en", fp16=False, sample_len=6)
+    assert len(out) == 3 and loads == ["tiny"], loads
