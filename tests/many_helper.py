@@ -134,3 +134,18 @@ def script_ragged_islands(indices, durations=(), seed=77):
             scripts[r].begin_window()
         set_row_scripts([scripts[r] for r in rows])
     streams.ON_GROUP_DECODE = on_group
+
+
+def script_batch_cpu(indices):
+    """CPU host-logic tests of transcribe_many(streams=N): in the worker process, the oracle-backed stand-ins for the kernels
+    (incl. the B-stream entries) once, then the scripted transcript for every recording of `indices`."""
+    global _STANDIN
+    if not _STANDIN:
+        import torch
+        import cpu_kernel_standin
+        from test_streams_host import install_streams_standin
+        torch.set_num_threads(4)
+        cpu_kernel_standin.install(_Patch())
+        install_streams_standin(_Patch())
+        _STANDIN = True
+    script_batch(indices)

@@ -364,3 +364,32 @@ def test_transcribe_many_two_worker_processes_on_the_cpu(monkeypatch):
         assert a["text"] == b["text"] and len(a["segments"]) == len(b["segments"]) > 0
         for sa, sb in zip(a["segments"], b["segments"]):
             assert sa["words"] == sb["words"]
+
+
+@pytest.mark.timeout(600)
+def test_transcribe_many_worker_processes_with_decoder_streams_and_warm_up(monkeypatch):
+    """transcribe_many(streams=2, warmup=True): every worker warms up on ONE recording of its batch through the
+    B-stream driver (not on its whole batch), meets the others at the barrier (timeout a parameter), then decodes its
+    recordings together -- same dictionaries as serial transcribe() calls."""
+    import torch
+    import many_helper as H
+    import cpu_kernel_standin
+    import whisper_timestamped as wt
+    from whisper_double.decoding import set_script
+    from whisper_timestamped.sharding import transcribe_many
+    g = torch.Generator().manual_seed(12)
+    audios = [(0.05 * torch.randn(n, generator=g)).float() for n in (30 * 16000, 21 * 16000, 26 * 16000, 18 * 16000)]
+    cpu_kernel_standin.install(monkeypatch)
+    model = H.load_tiny("cpu")
+    serial = []
+    for k, a in enumerate(audios):
+        H.script_clip(k)
+        serial.append(wt.transcribe(model, a, language="en", fp16=False))
+    set_script(None)
+    many, seconds = transcribe_many(H.load_tiny, audios, workers_per_gpu=2, devices=["cpu"], streams=2, warmup=True,
+                                    on_batch=H.script_batch_cpu, return_timing=True, barrier_timeout=300.0, language="en", fp16=False)
+    assert len(many) == len(serial) and seconds > 0
+    for a, b in zip(many, serial):
+        assert a["text"] == b["text"] and len(a["segments"]) == len(b["segments"]) > 0
+        for sa, sb in zip(a["segments"], b["segments"]):
+            assert [(w["text"], w["start"], w["end"]) for w in sa["words"]] == [(w["text"], w["start"], w["end"]) for w in sb["words"]]
