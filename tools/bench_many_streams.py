@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Worker processes x decoder streams on one GPU (sharding.transcribe_many(streams=N)): a B-stream decoder loop is bound by
-its one Python thread (DESIGN.md 6d), so W processes run W loops side by side.  30 s scripted clips, whisper-base shapes.
+its one Python thread (DESIGN.md 7), so W processes run W loops side by side.  30 s scripted clips, whisper-base shapes.
     python tools/bench_many_streams.py     -> one JSON line per (workers, streams)"""
 import json
 import os

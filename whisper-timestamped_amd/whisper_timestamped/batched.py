@@ -112,7 +112,7 @@ class BatchedAligner:
         self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
         # (Rounds 2-3 carried an opt-in replay of the forward pass as one captured HIP graph per shape.  Since round 3 the
         #  eager half-precision pass is GPU-bound -- 96 % busy in its own process -- so a replay could gain 4 % at most, and
-        #  it measured 1.4-2x SLOWER, 33-48 k against 66 k audio-s/s: removed in round 4)
+        #  it measured 1.4-2x SLOWER, 33-48 k against 66 k audio-s/s: removed in round 4, docs/history/DESIGN_rounds_1-4.md section 6a.)
         sot = tokenizer.sot_sequence
         if language and len(sot) == 3:                                   # :1230-1232
             sot = (sot[0], tokenizer.to_language_token(language), sot[2])

@@ -270,7 +270,7 @@ def _many_worker(rank, n_workers, devices, load_model, my_audios, mine, options,
     import os
     # W processes with the default intra-op thread count each (= every core of the host) fight for cores (the CPU test of
     # this function ran 7x faster with a share per worker); the decode loop is one Python thread.  On the GPU this is not
-    # what limits the scaling (DESIGN.md 8.2: the processes' small kernels serialise on the device)
+    # what limits the scaling (DESIGN.md 9: the processes' small kernels serialise on the device)
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // max(n_workers, 1))))
     dev = devices[rank % len(devices)]
     on_gpu = torch.device(dev).type == "cuda"      # (the CPU only ever appears in the host-logic tests)

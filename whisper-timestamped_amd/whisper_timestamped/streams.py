@@ -2,7 +2,7 @@
 
 The reference's efficient strategy (/root/reference/whisper_timestamped/transcribe.py:359-1001, "T.py" below) hooks
 openai-whisper's own ``transcribe()`` loop, which decodes ONE stream token by token (T.py:806 asserts a batch of one):
-on an MI355X that is ~2.7 ms of host Python per token around a few hundred microseconds of GPU work (DESIGN.md 8.2).
+on an MI355X that is ~2.7 ms of host Python per token around a few hundred microseconds of GPU work (DESIGN.md 7).
 Recordings are independent units, so here B of them step through the decoder TOGETHER:
 
   * a lock-step window driver: every round each active stream contributes its next 30 s window (its own seek, its own
