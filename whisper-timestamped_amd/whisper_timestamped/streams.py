@@ -13,10 +13,12 @@ Recordings are independent units, so here B of them step throug
     the build image: SURVEY.md Appendix C) for the option domain of the efficient strategy: greedy or single-temperature
     sampling, no temperature fallback, no beam (those go to the naive strategy: T.py:243-252), no ``vad``;
   * the data plane of the decode-time hooks for all streams of a decoder call: ONE ``wt_qk_rows_streams`` launch per
-    token writes the alignment heads' QK rows of every stream into its block of a (B, A_sel, n_ctx_text, 1500) ring,
-    ONE copy per token moves the (B, V) rows the sampler has just filtered into a (B, n_ctx_text + 1, V) ring, ONE
-    ``wt_logprob_gather_rows`` per decoder loop produces every stream's chosen-token log-probabilities, ONE
-    ``wt_find_start_padding_batch`` serves all windows of a round;
+    token writes the alignment heads' QK rows of every stream into its block of a (B, A_sel, sample_len + 1, 1500) ring,
+    ONE ``wt_logprob_digest_streams`` launch per token takes from the (B, V) rows the sampler has just filtered what the
+    hook state machine can still ask of them (the sampled token's log-probability, the argmax, max / log-sum-exp, the
+    raw logits of <|endoftext|> / <|notimestamps|> and of every timestamp token: 32 B + 6 KB per row -- the rows
+    themselves are not kept; round 4 kept them in a (B, 449, V) ring, 93 MB per stream), ONE host copy per decoder loop
+    brings every stream's digests, ONE ``wt_find_start_padding_batch`` serves all windows of a round;
   * per stream an unmodified ``EfficientSession`` (efficient.py: the reference's hook state machine, decision by
     decision) that is fed the RECORDED decoder calls of its stream -- the same methods in the same order as the live
     hooks would call them -- and whose alignment units go into ONE ``AlignmentBatch`` per window set (the sink).
