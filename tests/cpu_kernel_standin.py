@@ -13,8 +13,9 @@ from oracle import align_ref as O
 
 
 def install(monkeypatch):
-    from whisper_timestamped import _lib, alignment, capture, efficient
+    from whisper_timestamped import _lib, alignment, batched, capture, efficient
     monkeypatch.setattr(efficient, "GPU_FRONT_END", False)      # the backend's own torch.stft on the CPU
+    monkeypatch.setattr(batched, "SCHEDULE", "serial")          # no HIP streams on the CPU: everything in program order
     monkeypatch.setattr(efficient, "FUSED_ATTENTION", False)    # qk observed on the unfused path, as in the reference
 
     monkeypatch.setattr(_lib, "require_gpu", lambda device, what="": None)
@@ -39,7 +40,7 @@ def install(monkeypatch):
         return torch.tensor(out, dtype=torch.int32)
     monkeypatch.setattr(_lib, "find_start_padding", find_start_padding)
 
-    def logmel(pcm, mel_fb, n_valid_samples=None, n_frames=3000, with_padding=False):
+    def logmel(pcm, mel_fb, n_valid_samples=None, n_frames=3000, with_padding=False, launch=None):
         B = pcm.shape[0]
         M = mel_fb.shape[0]
         mel = torch.zeros((B, M, n_frames))

@@ -67,31 +67,32 @@ def guarded(t: torch.Tensor, mode: str) -> torch.Tensor:
 
 
 def guard_workload(w, mode):
+    import workloads as WL
     out = dict(w)
-    out.pop("_calls", None)
+    out.pop("batch", None)
     for k in ("qk", "logits", "tokens", "pcm", "n_valid", "fb", "descs_dev", "head_idx", "cost", "mel", "gmax", "pad", "result"):
         out[k] = guarded(w[k], mode)
     n_jumps = w["jumps"].numel()
     out["jumps"] = out["result"][:n_jumps]
     out["logprob"] = out["result"][n_jumps:].view(torch.float32)
-    return out
+    return WL.bind_batch(out)
 
 
 def case_step(workload, mode, n_chunks=None):
     """One bench step (log-mel, padding, cost, DTW, log-prob gather) with every buffer fenced."""
-    import bench
-    cfg = dict(bench.WORKLOADS[workload])
+    import workloads as WL
+    cfg = dict(WL.WORKLOADS[workload])
     if n_chunks:
         cfg["n_chunks"] = n_chunks
     dev = torch.device("cuda", 0)
-    w = bench.make_workload(dev, cfg, seed=77)
-    bench.run_step(w)
+    w = WL.make_workload(dev, cfg, seed=77)
+    WL.run_step(w)
     torch.cuda.synchronize()
     g = guard_workload(w, mode)
     for k in ("cost", "mel", "result"):
         g[k].fill_(0)
-    bench.run_step(g)
-    bench.run_step(g)           # (twice: the second call reuses the library's arenas)
+    WL.run_step(g)
+    WL.run_step(g)           # (twice: the second call reuses the library's arenas)
     torch.cuda.synchronize()
     for k in ("jumps", "mel", "pad", "gmax"):
         assert torch.equal(g[k], w[k]), f"{workload}/{mode}: {k} differs between fenced and ordinary buffers"

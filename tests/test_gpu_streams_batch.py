@@ -119,7 +119,7 @@ def test_thirty_two_ragged_streams_against_one_stream_each():
     0.02 s for at least 99 % of the words (a batch of 32 and a batch of 1 round differently inside the backend's GEMMs;
     a random-init model's flat attention turns that into a moved boundary where the script repeats a token: DESIGN.md 4)."""
     import numpy as np
-    import bench
+    import wordgaps as bench
     import many_helper as H
     import whisper_double as W
     from whisper_double.decoding import Script, set_row_scripts, set_script

@@ -241,6 +241,47 @@ def test_batched_aligner_whole_batch_equals_one_window_at_a_time(name, heads):
             assert np.allclose(x.numpy(), y.numpy(), rtol=0, atol=2e-4)
 
 
+def test_batched_aligner_on_stage_sets_equals_the_single_stream_run(monkeypatch):
+    """batched.SCHEDULE: the teacher-forced second pass with its stages on pipeline.StageSets (log-mel and DTW on a
+    high-priority HIP stream, model / cost / log-prob gather on a low-priority one, two sets alternating over the
+    sub-batches) against the same jobs with everything on the caller's stream: words, times and log-probabilities
+    BIT-identical (same kernels, same inputs, other streams), 12 windows in sub-batches of 4, three passes."""
+    import whisper_double as W
+    W.install()
+    from whisper_timestamped import batched
+    from whisper_timestamped.batched import BatchedAligner, WindowJob, align_windows
+    from whisper_timestamped.transcribe import get_alignment_heads
+    model = W.build_model("base", seed=2, device="cuda:0")
+    if hasattr(model, "alignment_heads"):
+        del model.alignment_heads
+    tk = W.tokenizer.get_tokenizer(True, num_languages=model.num_languages, language="en", task="transcribe")
+    g = torch.Generator().manual_seed(21)
+    ts0 = tk.timestamp_begin
+    jobs = []
+    for k in range(12):
+        n = int((14 + (5 * k) % 16) * 16000)
+        pcm = (torch.randn(n, generator=g) * 0.1).to("cuda:0")
+        toks = [ts0 + 2] + G.text_ids(700 + k, 30 + 7 * (k % 5)) + [ts0 + 400, ts0 + 420] + G.text_ids(800 + k, 25) + [ts0 + 650]
+        jobs.append(WindowJob(pcm, toks, n, tag=k))
+    kw = dict(language="en", alignment_heads=get_alignment_heads(model))
+    monkeypatch.setattr(batched, "SCHEDULE", "serial")
+    ref = list(align_windows(BatchedAligner(model, tk, **kw), jobs, 4))
+    monkeypatch.setattr(batched, "SCHEDULE", "hilo")
+    aligner = BatchedAligner(model, tk, **kw)
+    assert aligner.schedule == "hilo"
+    for _ in range(3):
+        got = list(align_windows(aligner, jobs, 4))
+        assert aligner._stage_sets is not None and aligner._launches >= 3
+        for a, b in zip(got, ref):
+            assert a.tag == b.tag and len(a.words) > 5
+            assert [(w["text"], w["start"], w["end"]) for w in a.words] == [(w["text"], w["start"], w["end"]) for w in b.words]
+            for x, y in zip(a.word_logprobs, b.word_logprobs):
+                assert torch.equal(x, y)
+    aligner.close()
+    monkeypatch.setattr(batched, "SCHEDULE", "auto")
+    assert BatchedAligner(model, tk, **kw).schedule == "hilo"          # the default: what transcribe(naive_approach=True) runs
+
+
 def test_transcribe_aligning_segment_by_segment(monkeypatch):
     """efficient.DEFER_ALIGNMENT = False: a synchronous alignment per flushed segment, as the reference does."""
     from whisper_timestamped import efficient

@@ -108,25 +108,25 @@ def test_gpu_results_validate_against_reference_schema():
         assert len(plain["segments"]) > 0
 
 
-def test_bench_schedules_are_well_formed():
-    """bench.SCHEDULES: every stage of the step has a stream and a priority level, every stage is issued exactly once, and
-    the DTW is issued after the cost stage it waits for (run_step_plan waits on an event recorded at issue time)."""
-    import bench
-    for name, plan in bench.SCHEDULES.items():
-        if plan is None:
-            continue
-        assert sorted(plan["order"]) == sorted(bench.STAGE_ORDER), name
-        assert set(plan["assign"]) == set(bench.STAGE_ORDER), name
-        assert plan["order"].index("cost") < plan["order"].index("dtw"), name
-        for stage, (key, level) in plan["assign"].items():
-            assert isinstance(key, str) and level in ("low", "normal", "high"), (name, stage)
+def test_pipeline_schedule_rule_and_lanes():
+    """whisper_timestamped.pipeline: every stage of the step has a lane; `auto` = hilo up to 128 units with separate cost / DTW
+    entries, serial beyond or with the fused small-unit entry; an explicit choice is kept; unknown names are refused."""
+    import pytest
+    from whisper_timestamped import pipeline as P
+    assert set(P.STAGES) <= set(P.LANE) and {P.LANE[s] for s in P.STAGES} == {"hi", "lo"}
+    assert P.LANE["dtw"] == P.LANE["logmel"] == "hi" and P.LANE["cost"] == P.LANE["logprob"] == "lo"
+    assert P.choose_schedule("auto", 32) == "hilo" and P.choose_schedule("auto", 128) == "hilo"
+    assert P.choose_schedule("auto", 256) == "serial" and P.choose_schedule("auto", 32, fused_small_units=True) == "serial"
+    assert P.choose_schedule("serial", 32) == "serial" and P.choose_schedule("hilo", 256) == "hilo"
+    with pytest.raises(AssertionError):
+        P.choose_schedule("two_streams", 32)
 
 
 def test_bench_word_gap_bookkeeping():
     """bench.word_gaps / merge_gaps / gaps_ok_between_batch_sizes: the per-word parity rule of the transcribe()-level legs
     (texts equal, confidences within 1e-4, mean log-probabilities within 2e-4, times within 0.02 s for >= 99 % of the words)."""
     import math
-    import bench
+    import wordgaps as bench
     a = [("w%d" % i, 0.5 * i, 0.5 * i + 0.4, 0.01 * (1 + i % 7)) for i in range(300)]
     same = bench.word_gaps(a, list(a), "same")
     assert same == [0.0, 0.0, 0.0, 300, 0] and bench.gaps_ok_between_batch_sizes(same)

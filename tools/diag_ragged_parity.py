@@ -13,7 +13,7 @@ for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-import bench  # noqa: E402
+import wordgaps  # noqa: E402
 import many_helper as H  # noqa: E402
 import whisper_double as W  # noqa: E402
 from whisper_double.decoding import Script, set_row_scripts, set_script  # noqa: E402
@@ -34,7 +34,7 @@ audios, wins, secs = [], [], []
 for k in range(B):
     sec = float(rs.uniform(5.0, 30.0))
     audios.append(clips[k % len(clips)][:int(sec * 16000)].clone())
-    wins.append([bench.ragged_window(rs, int(sec * 50), TS0, EOT)])
+    wins.append([H.ragged_window(rs, int(sec * 50), TS0, EOT)])
     secs.append(sec)
 
 
@@ -64,7 +64,7 @@ def one(k):
 a1, a2 = batch(B), batch(B)
 b1 = batch(1)
 c = [one(k) for k in range(B)]
-wo = bench.words_of
+wo = wordgaps.words_of
 print("B-stream run 1 == run 2 (times):", all([x[1:3] for x in wo(p)] == [x[1:3] for x in wo(q)] for p, q in zip(a1, a2)))
 print("streams driver, one stream at a time == transcribe():", all([x[1:3] for x in wo(p)] == [x[1:3] for x in wo(q)] for p, q in zip(b1, c)))
 n_words = n_diff = 0

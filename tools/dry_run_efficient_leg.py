@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
-import bench  # noqa: E402
+from benchlib.default_strategy_leg import run_efficient_leg  # noqa: E402
 import many_helper as H  # noqa: E402
 import cpu_kernel_standin  # noqa: E402
 from test_streams_host import install_streams_standin  # noqa: E402
@@ -22,5 +22,5 @@ install_streams_standin(patch)
 H.load_base = lambda device: H.load_tiny("cpu")
 torch.cuda.synchronize = lambda *a, **k: None
 args = types.SimpleNamespace(e2e_streams=int(sys.argv[1]) if len(sys.argv) > 1 else 4, no_cpu_baseline=True, e2e_device="cpu", e2e_islands=8)
-out = bench.run_efficient_leg(args, lambda o: None)
+out = run_efficient_leg(args, lambda o: None)
 print(json.dumps(out, indent=1)[:6000])

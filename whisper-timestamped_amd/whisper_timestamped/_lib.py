@@ -406,9 +406,11 @@ def qk_rows_batch(q_layers, k_layers, sel_layer, sel_head, sel_slot, ring: torch
 
 
 def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tensor | None = None, n_frames: int = 3000,
-           with_padding: bool = False):
+           with_padding: bool = False, launch=None):
     """pcm: (B, n_samples) fp32; mel_fb: (n_mels, 201) fp32.  Returns (mel (B,n_mels,n_frames), gmax (B,)) -- and, with
-    ``with_padding``, find_start_padding of every window (int32[B], -1 = None) by a one-wave-per-window pass that starts at the last valid column."""
+    ``with_padding``, find_start_padding of every window (int32[B], -1 = None) by a one-wave-per-window pass that starts at the last valid column.
+    ``launch``: a callable ``launch(fn)`` that runs ``fn(stream_handle)`` on a stream of its choice (pipeline.StageSet.run:
+    the outputs are allocated here, on the caller's current stream; the kernels go where the schedule puts them)."""
     _need_cuda(pcm, "pcm")
     pcm = pcm.contiguous().float()
     mel_fb = mel_fb.to(pcm.device).contiguous().float()
@@ -420,11 +422,17 @@ def logmel(pcm: torch.Tensor, mel_fb: torch.Tensor, n_valid_samples: torch.Tenso
     nv = None if n_valid_samples is None else n_valid_samples.to(device=pcm.device, dtype=torch.int32).contiguous()
     if with_padding:
         pad = torch.empty(B, dtype=torch.int32, device=pcm.device)
+
+        def go(st):
+            _check(load().wt_logmel_pad_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
+                                              gmax.data_ptr(), pad.data_ptr(), st), "wt_logmel_pad_batch")
         with on_device(pcm) as st:
-            rc = load().wt_logmel_pad_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
-                                            gmax.data_ptr(), pad.data_ptr(), st)
-        _check(rc, "wt_logmel_pad_batch")
+            if launch is not None:
+                launch(go)
+            else:
+                go(st)
         return mel, gmax, pad
+    assert launch is None, "launch=: only with with_padding=True"
     with on_device(pcm) as st:
         rc = load().wt_logmel_batch(pcm.data_ptr(), B, N, _ptr(nv), mel_fb.data_ptr(), M, n_frames, mel.data_ptr(),
                                     gmax.data_ptr(), st)

@@ -245,7 +245,7 @@ class AlignmentBatch:
     copy brings everything to the host."""
 
     def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False, workspace=None, extra_words=0,
-                 subwords_can_be_empty=True):
+                 subwords_can_be_empty=True, stage_set=None):
         self.units: list[AlignmentUnit] = []
         self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
         # transcribe.py:1571-1580: symmetric1, or the pattern without the previous-token/same-frame move
@@ -257,6 +257,10 @@ class AlignmentBatch:
         self.extra = None               # device int32 view of the caller's words (valid after launch())
         self._slot = self._order = None
         self._launched = self._fetched = False
+        # pipeline.StageSet: the cost stage on its low-priority stream (which must be the caller's CURRENT stream), the DTW
+        # on its high-priority one behind it by event -- for batches without small units (those take the fused tail kernel)
+        self.stage_set = stage_set
+        self._dtw_elsewhere = False
 
     def add(self, unit: AlignmentUnit | None):
         if unit is not None:
@@ -329,7 +333,22 @@ class AlignmentBatch:
                 self.path_len = torch.empty(n_units, dtype=torch.int32, device=dev)
                 self.dist = torch.empty(n_units, dtype=torch.float64, device=dev)
             L = _lib.load()
-            if self.step_pattern == _lib.WT_STEP_SYMMETRIC1:
+            ss = self.stage_set
+            if ss is not None and ss.hi is not ss.lo and not any(_lib.small_unit(u.T, u.F) for u in units):
+                assert ss.lo.cuda_stream == stream, "AlignmentBatch(stage_set=): launch() with the set's low-priority stream current"
+                dt_code = {torch.float32: 0, torch.float16: 1}[dt]
+                heads = slot.heads(n_sel).data_ptr()
+                ss.run("cost", lambda st_: _lib._check(L.wt_cost_batch(
+                    base, dt_code, descs.ctypes.data, descs_dev.data_ptr(), n_units, heads, n_sel, self.medfilt_width,
+                    float(self.qk_scale), cost.data_ptr(), st_), "wt_cost_batch"))
+                ss.run("dtw", lambda st_: _lib._check(L.wt_dtw_batch_pattern(
+                    cost.data_ptr(), descs.ctypes.data, descs_dev.data_ptr(), n_units, self.step_pattern, jumps.data_ptr(),
+                    _lib._ptr(self.path_i), _lib._ptr(self.path_j), _lib._ptr(self.path_len), _lib._ptr(self.dist), st_),
+                    "wt_dtw_batch_pattern"), after=("cost",))
+                self._dtw_elsewhere = True
+                if disfl:
+                    ss.wait_for(ss.lo, ("dtw",))
+            elif self.step_pattern == _lib.WT_STEP_SYMMETRIC1:
                 # units of the reference's per-segment shape take the fused small-unit kernel; their cost matrices only
                 # go to HBM when somebody reads them afterwards (keep_cost, the disfluency kernel)
                 flags = (_lib.WT_ALIGN_KEEP_COST if (self.keep_cost or disfl) else 0) | \
@@ -382,6 +401,8 @@ class AlignmentBatch:
         self._fetched = True
         slot = self._slot
         with torch.cuda.device(slot.device):
+            if self._dtw_elsewhere:                  # the jumps come from the set's other stream
+                self.stage_set.wait_for(torch.cuda.current_stream(slot.device), ("dtw",))
             slot.result_host[:self._n_result].copy_(slot.result[:self._n_result], non_blocking=True)
             slot.event.record(torch.cuda.current_stream(slot.device))
         return self

@@ -97,12 +97,14 @@ def log_mel_spectrogram(audio, n_mels: int = 80, padding: int = 0, device=None) 
     return mel[0]
 
 
-def log_mel_batch(pcm: torch.Tensor, n_valid_samples=None, n_mels: int = 80, n_frames: int = N_FRAMES, with_padding: bool = False):
+def log_mel_batch(pcm: torch.Tensor, n_valid_samples=None, n_mels: int = 80, n_frames: int = N_FRAMES, with_padding: bool = False,
+                  launch=None):
     """(B, n_samples) crops -> (B, n_mels, n_frames), each crop normalised by its
     own max and zero-padded like log_mel_spectrogram + pad_or_trim per crop.  ``with_padding``: also find_start_padding
     of every window (int32[B] on the device, -1 = None), from a one-wave-per-window pass behind it (wt_logmel_pad_batch)."""
     if with_padding:
-        mel, _, pad = _lib.logmel(pcm, mel_filters(pcm.device, n_mels), n_valid_samples, n_frames=n_frames, with_padding=True)
+        mel, _, pad = _lib.logmel(pcm, mel_filters(pcm.device, n_mels), n_valid_samples, n_frames=n_frames, with_padding=True,
+                                  launch=launch)
         return mel, pad
     mel, _ = _lib.logmel(pcm, mel_filters(pcm.device, n_mels), n_valid_samples, n_frames=n_frames)
     return mel

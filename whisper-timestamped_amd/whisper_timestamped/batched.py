@@ -21,6 +21,12 @@ exists in the other branch (:1147-1152) -- so B of them can share every launch:
 ``align_windows`` is that pipeline; ``naive.transcribe_naive`` hands it the windows of one recording,
 ``bench.py`` 32 synthetic chunks (BASELINE.json configs[1] at the transcribe() level).  Sub-batches are pipelined:
 the GPU work of sub-batch k+1 is queued before the host assembles the words of sub-batch k.
+
+Streams (``SCHEDULE``; whisper_timestamped/pipeline.py): sub-batch k runs on StageSet k % 2 -- the model's GEMMs, the QK-row
+pass, the cost stage and the log-probability gather on the set's low-priority HIP stream, the log-mel front end and the
+DTW on its high-priority one, dependencies as events -- so the latency-bound DTW and the VALU-bound STFT of one sub-batch
+run beside the other kernels instead of in front of them.  ``SCHEDULE = "serial"`` keeps everything on the caller's
+current stream (what rounds 1-5 did); results are bit-identical either way (tests/test_gpu_transcribe.py).
 """
 from __future__ import annotations
 
@@ -30,7 +36,7 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
-from . import _lib, audio as wt_audio, backend
+from . import _lib, audio as wt_audio, backend, pipeline
 from .alignment import AlignmentBatch, default_workspace, head_pairs, planned_words, prepare_unit, set_padding
 from .capture import layer_head_slots
 from .confidence import strip_trailing_punctuation
@@ -40,6 +46,7 @@ logger = logging.getLogger("whisper_timestamped")
 
 N_SAMPLES = N_FRAMES * HOP_LENGTH     # 480000: one 30 s window
 MAX_WINDOWS_PER_LAUNCH = 32           # BASELINE.json configs[1]; bounds the (B, T_max, V) logits block (base: 0.6 GB)
+SCHEDULE = "auto"                     # pipeline.choose_schedule: "auto" | "hilo" | "serial" (serial = the caller's current stream)
 
 
 @dataclass
@@ -110,6 +117,8 @@ class BatchedAligner:
         self.n_mels = model.dims.n_mels if hasattr(model.dims, "n_mels") else 80
         self.workspace = default_workspace(self.dev)
         self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
+        self.schedule = pipeline.choose_schedule(SCHEDULE, MAX_WINDOWS_PER_LAUNCH)
+        self._stage_sets, self._launches = None, 0
         # (Rounds 2-3 carried an opt-in replay of the forward pass as one captured HIP graph per shape.  Since round 3 the
         #  eager half-precision pass is GPU-bound -- 96 % busy in its own process -- so a replay could gain 4 % at most, and
         #  it measured 1.4-2x SLOWER, 33-48 k against 66 k audio-s/s: removed in round 4, docs/history/DESIGN_rounds_1-4.md section 6a.)
@@ -138,13 +147,32 @@ class BatchedAligner:
         keep.append(up)
         return up.dev
 
-    def _mark(self, st, name):
+    def _mark(self, st, name, stream=None):
         """Timeline (bench.py): an event pair around every stage's launches -- the pair times the stage's kernels only,
         not the time the GPU may have waited for the host to queue them."""
         if self.timeline is not None:
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record(torch.cuda.current_stream(self.dev))
+            ev.record(stream if stream is not None else torch.cuda.current_stream(self.dev))
             st.marks.append((name, ev))
+
+    def _next_stage_set(self):
+        """StageSet of the next sub-batch (two, alternating), or None under the serial schedule."""
+        if self.schedule != "hilo":
+            return None
+        if self._stage_sets is None:
+            with _lib.device_ctx(self.dev):
+                self._stage_sets = [pipeline.StageSet(self.dev, "hilo") for _ in range(2)]
+        self._launches += 1
+        return self._stage_sets[self._launches % 2]
+
+    def close(self):
+        """Free the library's scratch arenas of the aligner's own streams (after the last collect())."""
+        if self._stage_sets is not None:
+            with _lib.device_ctx(self.dev):
+                for s in self._stage_sets:
+                    s.synchronize()
+                    s.release()
+            self._stage_sets = None
 
     # ------------------------------------------------------------------ the model's forward pass
     def _forward(self, x, tok_dev):
@@ -169,6 +197,15 @@ class BatchedAligner:
 
     # ------------------------------------------------------------------ device: one sub-batch, nothing waits
     def launch(self, jobs) -> _Stage:
+        ss = self._next_stage_set()
+        if ss is None:
+            return self._launch(jobs, None)
+        with _lib.device_ctx(self.dev):
+            ss.lo.wait_stream(torch.cuda.current_stream(self.dev))      # the jobs' PCM was produced on the caller's stream
+            with torch.cuda.stream(ss.lo):                              # every buffer of the sub-batch belongs to this stream
+                return self._launch(jobs, ss)
+
+    def _launch(self, jobs, ss) -> _Stage:
         tk, dev = self.tk, self.dev
         st = _Stage(jobs=list(jobs))
         B = len(st.jobs)
@@ -193,11 +230,23 @@ class BatchedAligner:
                 pcm[b, :n_valid[b]].copy_(job.pcm.reshape(-1), non_blocking=True)
             small = self._to_device(np.concatenate([tok_mat.reshape(-1), n_valid]), st.keep)
             tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
-            self._mark(st, "logmel<")
             # log-mel of every crop, zero padded to 3000 frames (:1211-1215), and where the padding starts (:1795-1805)
-            mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True)
-            pad_copy = _lib.HostCopy(pad)
-            self._mark(st, "logmel>")
+            if ss is None:
+                self._mark(st, "logmel<")
+                mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True)
+                pad_copy = _lib.HostCopy(pad)
+                self._mark(st, "logmel>")
+            else:
+                # on the set's high-priority stream, behind the uploads; the model waits for it by event
+                ss.run("upload", lambda st_: None)
+                ss.wait_for(ss.hi, ("upload",))
+                self._mark(st, "logmel<", ss.hi)
+                mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True,
+                                                  launch=lambda fn: ss.run("logmel", fn))
+                with torch.cuda.stream(ss.hi):
+                    pad_copy = _lib.HostCopy(pad)
+                self._mark(st, "logmel>", ss.hi)
+                ss.wait_for(ss.lo, ("logmel",))
             del pcm
             self._mark(st, "model<")
             # encoder + teacher-forced decoder on the whole batch (:1236-1238); no logit filters on this path (:1245)
@@ -247,14 +296,20 @@ class BatchedAligner:
                 st.plans.append(plan)
             # where each window's zero padding starts: queued right behind the log-mel, long since on the host
             pad_host = pad_copy.wait()
-            batch = AlignmentBatch(workspace=self.workspace, extra_words=n_gather)
+            batch = AlignmentBatch(workspace=self.workspace, extra_words=n_gather, stage_set=ss)
             for b, u in enumerate(st.units):
                 if u is not None:
                     set_padding(u, None if int(pad_host[b]) < 0 else int(pad_host[b]))
                 batch.add(u)
             self._mark(st, "align<")
+            if ss is not None:
+                ss.start_timeline(self.timeline is not None)
             batch.launch()
             self._mark(st, "align>")
+            if ss is not None and ss.timeline:
+                # the DTW ran on the set's other stream: its own event pair (start = its cost stage done)
+                st.marks.extend(m for stage, ev0, ev1 in ss.timeline if stage == "dtw" for m in (("dtw<", ev0), ("dtw>", ev1)))
+                ss.start_timeline(False)
             self._mark(st, "logprob<")
             if n_gather and batch.units:
                 gt = self._to_device(np.concatenate([np.asarray(gather_rows, dtype=np.int32),

@@ -364,11 +364,14 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
                                      compute_word_confidence=compute_word_confidence,
                                      include_punctuation_in_confidence=include_punctuation_in_confidence,
                                      detect_disfluencies=detect_disfluencies, fused_attention=FUSED_ATTENTION)
-            for res in align_windows(aligner, pending, BATCH_WINDOWS):
-                start, i_segment, segment, t2s = res.tag
-                check = [] if res.first_token_check is None else [res.first_token_check]
-                finish_window(res.words, res.word_logprobs, res.tokens, start, i_segment, segment, t2s, check,
-                              res.last_token_check)
+            try:
+                for res in align_windows(aligner, pending, BATCH_WINDOWS):
+                    start, i_segment, segment, t2s = res.tag
+                    check = [] if res.first_token_check is None else [res.first_token_check]
+                    finish_window(res.words, res.word_logprobs, res.tokens, start, i_segment, segment, t2s, check,
+                                  res.last_token_check)
+            finally:
+                aligner.close()            # its own HIP streams (pipeline.StageSet) and their scratch arenas
     finally:
         for h in hooks:
             h.remove()
