@@ -8,10 +8,12 @@ module with stub modules for the third-party packages that are absent here:
   * ``whisper``  -- only what transcribe.py touches at import time
                     (``__version__``, ``utils.format_timestamp``, ``audio``
                     constants, ``model.disable_sdpa``);
-  * ``dtw``      -- ``dtw.dtw`` / ``dtw.stepPattern.symmetric1`` backed by the
-                    oracle's C restatement of dtw-python (oracle/dtw_ref.c).
-                    The stub also RECORDS the local-cost matrix the reference
-                    hands to it, which is how the f64 cost built by
+  * ``dtw``      -- ``dtw.dtw`` / ``dtw.stepPattern`` backed by the oracle's generic
+                    step-pattern interpreter (oracle/dtw_patterns.py): the reference's own
+                    ``StepPattern(_c(...))`` expression (transcribe.py:1575-1580) is executed,
+                    its rows interpreted; every call is cross-checked against the C
+                    restatement (oracle/dtw_ref.c).  The stub also RECORDS the local-cost
+                    matrix the reference hands to it, which is how the f64 cost built by
                     transcribe.py:1540-1568 is captured.
 
 Everything else (scipy.ndimage.median_filter, torch CPU ops, jumps, word
@@ -62,25 +64,16 @@ def load_reference():
     w.utils, w.audio, w.model = wu, wa, wm
     sys.modules.update({"whisper": w, "whisper.utils": wu, "whisper.audio": wa, "whisper.model": wm})
 
-    d = types.ModuleType("dtw")
-    sp = types.ModuleType("dtw.stepPattern")
-    sp.symmetric1 = "symmetric1"
-    # the pattern the reference builds itself for subwords_can_be_empty=False (transcribe.py:1575-1580): rows of
-    # (pattern number, token step, frame step, weight) -- recognised here by its rows
-    sp._c = lambda *rows: tuple(rows)
-    sp.StepPattern = lambda rows: ("custom",) + tuple(rows)
-    d.stepPattern = sp
-    NO_EMPTY = ("custom", 1, 1, 1, -1, 1, 0, 0, 1, 2, 0, 1, -1, 2, 0, 0, 1)
+    from oracle import dtw_patterns as P
 
-    def dtw_stub(x, step_pattern=None, **kw):
-        assert step_pattern in ("symmetric1", NO_EMPTY), step_pattern
+    def record(x, res):
         _captured["cost"] = np.array(x, dtype=np.float64, copy=True)
-        res = O.dtw_ref(x, step_pattern=0 if step_pattern == "symmetric1" else 1)
         _captured["index1s"], _captured["index2s"] = res.index1s, res.index2s
-        return res
 
-    d.dtw = dtw_stub
-    sys.modules.update({"dtw": d, "dtw.stepPattern": sp})
+    def c_restatement(x, pattern):          # the hard-coded form: 3 moves = symmetric1, 2 moves = the reference's own pattern
+        r = O.dtw_ref(x, step_pattern=0 if pattern.n_patterns == 3 else 1)
+        return r.index1s, r.index2s
+    sys.modules.update(P.stub_modules(on_call=record, cross_check=c_restatement))
 
     spec = importlib.util.spec_from_file_location("ref_transcribe", REF)
     mod = importlib.util.module_from_spec(spec)

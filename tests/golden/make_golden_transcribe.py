@@ -7,7 +7,8 @@ unmodified) in the build container, on the CPU, against
     openai-whisper is not installed; see that package's docstring), with
     random-initialised models and SCRIPTED sampling so that every branch of the
     hook state machine is reached deterministically;
-  * a ``dtw`` stub backed by oracle/dtw_ref.c (dtw-python is not installed).
+  * a ``dtw`` stub backed by oracle/dtw_patterns.py, the generic step-pattern interpreter, cross-checked per call
+    against oracle/dtw_ref.c (dtw-python is not installed).
 
 The GPU tests (tests/test_gpu_transcribe.py) rebuild the same model / audio /
 script from the case parameters and compare this repository's ``transcribe``
@@ -222,6 +223,35 @@ def case_list():
                           window_script(EN, EOT_EN, [seg(95, 0, 6, 800)], "pair"),
                           window_script(EN, EOT_EN, [seg(96, 30, 9, 600), seg(97, 610, 6, 1300)], "pair"),
                           window_script(EN, EOT_EN, [seg(98, 10, 5, 350)], "eot")]))
+    # ---- the "peaked" double (whisper_double.model.sharpen_cross_attention): cross-attention with a monotone ridge on the
+    #      alignment heads, as a trained model has, and scripts whose timestamps follow it (many_helper.peaked_segments) --
+    #      the cases above run on plain random-init weights, whose flat attention leaves the DTW little to decide on
+    import many_helper as H
+
+    def pseg(seed, counts, first_pos=3):
+        return [(s, text_ids(seed + k, n) if (seed + k) % 2 else [None] * n, e)
+                for k, (s, n, e) in enumerate(H.peaked_segments(counts, first_pos))]
+
+    C.append(dict(name="peaked_one_window", model="tiny", attention="peaked", audio_s=14.0, audio_seed=41,
+                  opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, pseg(101, [9, 14, 7, 11, 16]), "eot")]))
+    C.append(dict(name="peaked_two_windows_no_condition", model="tiny", attention="peaked", audio_s=49.0, audio_seed=42,
+                  opts=dict(language="en", condition_on_previous_text=False),
+                  script=[window_script(ML, EOT_ML, pseg(111, [12, 20, 9, 25, 14, 18, 30, 11]), "pair"),
+                          window_script(ML, EOT_ML, pseg(121, [10, 8, 15]), "eot")]))
+    C.append(dict(name="peaked_base_table_heads", model="base", attention="peaked", drop_alignment_heads=True, audio_s=22.0,
+                  audio_seed=43, opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, pseg(131, [17, 22, 13, 28, 19, 24]), "eot")]))
+    C.append(dict(name="peaked_full_window_disfluencies", model="tiny", attention="peaked", audio_s=30.0, audio_seed=44,
+                  opts=dict(language="en", detect_disfluencies=True),
+                  script=[window_script(ML, EOT_ML, pseg(141, [21, 35, 18, 40, 27, 33, 22]), "eot")]))
+    C.append(dict(name="peaked_naive_no_trust", model="tiny", attention="peaked", audio_s=27.0, audio_seed=45,
+                  opts=dict(language="en", naive_approach=True, trust_whisper_timestamps=False),
+                  script=[window_script(ML, EOT_ML, pseg(151, [15, 26, 12, 31, 20]), "eot")]))
+    C.append(dict(name="peaked_conditioned_second_window", model="tiny", attention="peaked", audio_s=52.0, audio_seed=46,
+                  opts=dict(language="en"),
+                  script=[window_script(ML, EOT_ML, pseg(161, [14, 19, 23, 12, 17]), "pair"),
+                          window_script(ML, EOT_ML, pseg(171, [11, 16, 9]), "eot")]))
     return C
 
 
@@ -229,7 +259,7 @@ def build_case(c, device="cpu"):
     """-> (model, audio tensor on the CPU, Script)"""
     import whisper_double as W
     from whisper_double.decoding import Script
-    model = W.build_model(c["model"], seed=c.get("model_seed", 0), device=device)
+    model = W.build_model(c["model"], seed=c.get("model_seed", 0), device=device, attention=c.get("attention", "flat"))
     if c.get("drop_alignment_heads"):
         del model.alignment_heads
     g = torch.Generator().manual_seed(1000 + c["audio_seed"])
@@ -273,12 +303,12 @@ def load_reference():
     import whisper_double as W
     from oracle import align_ref as O
     W.install()
-    d = types.ModuleType("dtw")
-    sp = types.ModuleType("dtw.stepPattern")
-    sp.symmetric1 = "symmetric1"
-    d.stepPattern = sp
-    d.dtw = lambda x, step_pattern=None, **kw: O.dtw_ref(x)
-    sys.modules.update({"dtw": d, "dtw.stepPattern": sp})
+    from oracle import dtw_patterns as P
+
+    def c_restatement(x, pattern):
+        r = O.dtw_ref(x, step_pattern=0 if pattern.n_patterns == 3 else 1)
+        return r.index1s, r.index2s
+    sys.modules.update(P.stub_modules(cross_check=c_restatement))
     spec = importlib.util.spec_from_file_location("ref_transcribe", REF)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

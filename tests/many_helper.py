@@ -9,16 +9,21 @@ for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT
         sys.path.insert(0, p)
 
 
-def load_base(device):
+def load_base(device, attention="flat"):
     import whisper_double as W
     W.install()
-    return W.build_model("base", seed=0, device=device)
+    return W.build_model("base", seed=0, device=device, attention=attention)
 
 
-def load_tiny(device):
+def load_base_peaked(device):
+    """whisper-base dims whose alignment heads attend along a monotone ridge (whisper_double.model.sharpen_cross_attention)."""
+    return load_base(device, attention="peaked")
+
+
+def load_tiny(device, attention="flat"):
     import whisper_double as W
     W.install()
-    return W.build_model("tiny", seed=0, device=device)
+    return W.build_model("tiny", seed=0, device=device, attention=attention)
 
 
 SEGMENTS = [(0, 20, 280), (300, 22, 600), (620, 18, 900), (920, 21, 1200), (1220, 19, 1490)]   # (start frame, text tokens, end frame)
@@ -114,19 +119,57 @@ def ragged_window(rs, frames, ts0, eot, lo=40, hi=160):
     return G.window_script(ts0, eot, segs, "eot")
 
 
-def ragged_island_windows(durations, seed=77, ts0=50364, eot=50257):
+def peaked_segments(counts, first_pos=3, stride=None, pause=0):
+    """[(start frame, n text tokens, end frame)] for segments of `counts` text tokens whose timestamps follow the ridge of
+    the "peaked" double: the script token at decoder position q is predicted from position q - 1, whose cross-attention
+    peaks at frame (q - 1) * stride; a segment <|s|> text x n <|e|> starting at position q0 spans frames
+    [q0 * stride, (q0 + n + 1) * stride].  first_pos = length of the prompt in front of the script (3: sot, language, task);
+    pause = extra positions' worth of silence between segments (moves the timestamps, not the ridge)."""
+    from whisper_double.model import PEAK_STRIDE
+    stride = stride or PEAK_STRIDE
+    segs, q = [], first_pos
+    for n in counts:
+        segs.append((q * stride, int(n), (q + int(n) + 1) * stride))
+        q += int(n) + 2
+    return segs
+
+
+def peaked_window(rs, frames, ts0, eot, lo=40, hi=160, first_pos=3):
+    """ragged_window for the "peaked" double: 2-9 segments, 40-160 text tokens (fewer where the window is short: one
+    position is PEAK_STRIDE frames), timestamps placed where the model's attention ridge is (peaked_segments)."""
+    import numpy as np
+    from golden import make_golden_transcribe as G
+    from whisper_double.model import PEAK_STRIDE
+    n_seg = int(rs.randint(2, 10))
+    room = (frames - 2) // PEAK_STRIDE - first_pos - 2 * n_seg - 1          # positions left for text tokens
+    while room < 3 * n_seg and n_seg > 1:
+        n_seg -= 1
+        room = (frames - 2) // PEAK_STRIDE - first_pos - 2 * n_seg - 1
+    total = max(3 * n_seg, min(int(rs.randint(lo, hi + 1)), room))
+    total = min(total, max(room, n_seg))
+    share = rs.dirichlet(np.full(n_seg, 2.0))
+    counts = [max(3, int(round(x * total))) for x in share]
+    while sum(counts) > max(room, 3 * n_seg):
+        counts[int(np.argmax(counts))] -= 1
+    segs = [(s0, G.text_ids(int(rs.randint(1 << 30)), 2) + [None] * (n - 2), min(e0, frames - 1))
+            for s0, n, e0 in peaked_segments(counts, first_pos)]
+    return G.window_script(ts0, eot, segs, "eot")
+
+
+def ragged_island_windows(durations, seed=77, ts0=50364, eot=50257, peaked=False):
     """Per island (duration in seconds, a multiple of 30) one ragged window script per 30 s window."""
     import numpy as np
     rs = np.random.RandomState(seed)
-    return [[ragged_window(rs, 1500, ts0, eot) for _ in range(int(d) // 30)] for d in durations]
+    make = peaked_window if peaked else ragged_window
+    return [[make(rs, 1500, ts0, eot) for _ in range(int(d) // 30)] for d in durations]
 
 
-def script_ragged_islands(indices, durations=(), seed=77):
+def script_ragged_islands(indices, durations=(), seed=77, peaked=False):
     """transcribe_many(streams=N, on_batch=functools.partial(script_ragged_islands, durations=...)): in a worker process,
     the ragged scripts of ITS islands (`indices` = positions in the caller's list, in stream order)."""
     from whisper_double.decoding import Script, set_row_scripts
     from whisper_timestamped import streams
-    windows = ragged_island_windows(durations, seed)
+    windows = ragged_island_windows(durations, seed, peaked=peaked)
     scripts = [Script(windows[i]) for i in indices]
 
     def on_group(rows):

@@ -116,6 +116,43 @@ def test_dtw_bit_exact_positive_and_mixed_sign_costs():
     assert dist == acc
 
 
+def test_dtw_kernel_equals_the_pattern_interpreter_on_tie_sets():
+    """The HIP kernel against oracle/dtw_patterns.py -- the generic step-pattern interpreter that consumes the rows the
+    reference builds (transcribe.py:1575-1580) and dtw-python's published symmetric1 rows -- on tie-decided matrices
+    (zeros, quantised levels, pad-mask plateaus, mixed sign), both step patterns: paths, jumps and distances bit-exact.
+    (A second restatement, structurally unlike oracle/dtw_ref.c, while dtw-python itself cannot be installed.)"""
+    from oracle import dtw_patterns as P
+    from test_oracle import _tie_sets
+    L = _lib()
+    rng = np.random.RandomState(31)
+    costs = [c.astype(np.float32) for c in _tie_sets(rng, 80, max_t=70, max_f=160)]
+    got = run_dtw(costs)
+    for c, (jm, pi, pj, dist) in zip(costs, got):
+        r = P.dtw(c.astype(np.float64))
+        assert np.array_equal(pi, r.index1s) and np.array_equal(pj, r.index2s), c.shape
+        assert np.array_equal(jm, O.jumps_from_path(r.index1s, r.index2s)) and dist == r.distance
+    no_empty = P.StepPattern(P._c(1, 1, 1, -1, 1, 0, 0, 1, 2, 0, 1, -1, 2, 0, 0, 1))
+    costs = [c for c in costs if c.shape[0] <= c.shape[1]]
+    descs = L.make_descs(len(costs))
+    for d, c in zip(descs, costs):
+        d["T"], d["F"] = c.shape
+        d["pad_from"] = -1
+    n_cost, n_jumps, n_path = L.layout_outputs(descs)
+    flat = np.zeros(n_cost, dtype=np.float32)
+    for d, c in zip(descs, costs):
+        flat[d["cost_offset"]:d["cost_offset"] + c.size] = c.ravel()
+    jumps = torch.zeros(n_jumps, dtype=torch.int32, device=DEV)
+    dist = torch.zeros(len(costs), dtype=torch.float64, device=DEV)
+    L.dtw_batch(torch.from_numpy(flat).to(DEV), descs, L.descs_to_device(descs, DEV), jumps, dist=dist,
+                step_pattern=L.WT_STEP_NO_EMPTY_SUBWORDS)
+    jumps, dist = jumps.cpu().numpy(), dist.cpu().numpy()
+    for k, (d, c) in enumerate(zip(descs, costs)):
+        r = P.dtw(c.astype(np.float64), step_pattern=no_empty)
+        j0 = int(d["jumps_offset"])
+        assert np.array_equal(jumps[j0:j0 + c.shape[0] + 1], O.jumps_from_path(r.index1s, r.index2s)), c.shape
+        assert dist[k] == r.distance
+
+
 def test_dtw_bit_exact_max_sizes():
     rng = np.random.RandomState(2)
     costs = [(-rng.rand(256, 1500)).astype(np.float32), (-rng.rand(224, 1500)).astype(np.float32),

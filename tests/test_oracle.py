@@ -101,6 +101,82 @@ def test_dtw_vs_transformers_on_tie_free_inputs():
         assert np.array_equal(np.asarray(ti), r.index1s) and np.array_equal(np.asarray(tj), r.index2s)
 
 
+def _tie_sets(rng, n, max_t=40, max_f=90):
+    """Cost matrices on which the direction choice is decided by TIE ORDER: zeros, constants, quantised levels, the
+    reference's pad-mask plateau (rows [:-1] zero from a column on), mixed sign."""
+    out = [np.zeros((3, 5)), np.zeros((7, 7)), -np.ones((5, 11)), np.ones((4, 9))]
+    for _ in range(n):
+        T, F = int(rng.randint(1, max_t)), int(rng.randint(1, max_f))
+        kind = rng.randint(4)
+        if kind == 0:
+            c = -(rng.randint(0, 4, size=(T, F)) / 4.0)
+        elif kind == 1:
+            c = rng.randint(-2, 3, size=(T, F)) / 2.0
+        elif kind == 2:
+            c = -rng.rand(T, F)
+            if T > 1:
+                c[:-1, int(F * rng.rand()):] = 0.0
+        else:
+            c = np.round(rng.standard_normal((T, F)), 1)
+        if rng.rand() < 0.5:
+            c[0, 0] = c.min()
+        out.append(c.astype(np.float64))
+    return out
+
+
+def test_dtw_pattern_interpreter_equals_the_c_restatement():
+    """oracle/dtw_patterns.py (generic loops over the pattern ROWS, as dtw-python's computeCM / backtrack run them) against
+    oracle/dtw_ref.c (the two patterns hard-coded): same paths, same distances, bit for bit -- both step patterns, on
+    tie-decided matrices.  The rows of the second pattern are the ones the reference passes at transcribe.py:1575-1580."""
+    from oracle import dtw_patterns as P
+    rng = np.random.RandomState(7)
+    no_empty = P.StepPattern(P._c(1, 1, 1, -1,
+                                  1, 0, 0, 1,
+                                  2, 0, 1, -1,
+                                  2, 0, 0, 1))
+    for c in _tie_sets(rng, 120):
+        for code, pat in ((0, P.symmetric1), (1, no_empty)):
+            if code == 1 and c.shape[0] > c.shape[1]:
+                with pytest.raises(ValueError):
+                    P.dtw(c, step_pattern=pat)
+                with pytest.raises(ValueError):
+                    O.dtw_ref(c, step_pattern=1)
+                continue
+            a = P.dtw(c, step_pattern=pat)
+            b = O.dtw_ref(c, step_pattern=code)
+            assert np.array_equal(a.index1s, b.index1s) and np.array_equal(a.index2s, b.index2s), (code, c.shape)
+            assert a.distance == b.distance
+
+
+def test_dtw_pattern_interpreter_sees_a_swapped_tie_order():
+    """Mutation: the same rows with patterns 2 and 3 exchanged (previous-token/same-frame tried before same-token/
+    previous-frame) must give OTHER paths on tie-decided matrices -- i.e. the comparison above can tell the orders apart --
+    and the same optimal distance (the set of moves is unchanged)."""
+    from oracle import dtw_patterns as P
+    swapped = P.StepPattern(P._c(1, 1, 1, -1, 1, 0, 0, 1,
+                                 2, 1, 0, -1, 2, 0, 0, 1,
+                                 3, 0, 1, -1, 3, 0, 0, 1))
+    rng = np.random.RandomState(8)
+    differ = 0
+    sets = _tie_sets(rng, 60)
+    for c in sets:
+        a, b = P.dtw(c, step_pattern=P.symmetric1), P.dtw(c, step_pattern=swapped)
+        assert np.isclose(a.distance, b.distance, rtol=0, atol=1e-9)
+        differ += not (np.array_equal(a.index1s, b.index1s) and np.array_equal(a.index2s, b.index2s))
+        ref = O.dtw_ref(c)
+        assert np.array_equal(a.index1s, ref.index1s) and np.array_equal(a.index2s, ref.index2s)
+    assert differ >= len(sets) // 4, differ             # (a third of the matrices of this seed: 22 of 64)
+
+
+def test_dtw_pattern_interpreter_optimal_cost_vs_exhaustive_recurrence():
+    from oracle import dtw_patterns as P
+    rng = np.random.RandomState(9)
+    for _ in range(100):
+        T, F = rng.randint(1, 7), rng.randint(1, 10)
+        c = -rng.rand(T, F)
+        assert np.isclose(P.dtw(c).distance, O.dtw_bruteforce_cost(c), rtol=0, atol=1e-12)
+
+
 def test_dtw_rejects_nan():
     c = np.zeros((3, 4)); c[1, 2] = np.nan
     with pytest.raises(ValueError):

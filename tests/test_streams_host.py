@@ -296,7 +296,7 @@ def test_window_bookkeeping_equals_the_backends_loop_on_random_token_streams():
 
 @pytest.mark.parametrize("seed,extra_opts", [(2024, None), (7, {"trust_whisper_timestamps": False}), (11, {"detect_disfluencies": True})],
                          ids=["defaults", "no_trust", "disfluencies"])
-def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, extra_opts, device="cpu", time_tol=0.0, hold=0, n_wins=None):
+def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, extra_opts, device="cpu", time_tol=0.0, n_wins=None):
     """Beyond the goldens: recordings with RANDOM scripted transcripts -- one to three windows, segments of random sizes,
     every ending the decoder can produce (closing timestamp, timestamp pair, no closing timestamp, token budget hit) --
     through transcribe_batch (three ring blocks for eight recordings: continuous admission, ragged rounds, groups by
@@ -311,7 +311,6 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
         cpu_kernel_standin.install(monkeypatch)
         install_streams_standin(monkeypatch)
     monkeypatch.setattr(words, "RAW_CONFIDENCE", True)     # (before the reference's round(, 3): a rounding flip is not a difference)
-    monkeypatch.setattr(streams, "HOLD_FOR_BUCKET", hold)
     rng = np.random.RandomState(seed)
     ML, EOT = 50364, 50257
     model = W.build_model("tiny", seed=0, device=device)
@@ -358,7 +357,6 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
         set_row_scripts(None)
     assert streams.LAST_RUN["ring_blocks"] == 3 and (streams.LAST_RUN["admissions"] >= 3 or n_wins is not None)
     assert sum(streams.LAST_RUN["streams_per_loop"]) >= len(recs) and len(streams.LAST_RUN["streams_per_loop"]) == streams.LAST_RUN["decoder_loops"]
-    assert (streams.LAST_RUN["windows_held_one_round"] > 0) == (hold > 1)
     n_words = 0
     for b, s_, sc, rec in zip(batch, singles, scripts, recorded):
         assert sc.record == rec
@@ -368,11 +366,60 @@ def test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, seed, ex
     assert n_words > (40 if n_wins is None else 10)
 
 
-def test_bucket_admission_does_not_change_any_result(monkeypatch):
-    """HOLD_FOR_BUCKET: streams whose prompt length nobody shares sit a round out -- same dictionaries as one stream at a time."""
-    # three ring blocks; A has two windows, the others one: in round 2 A's second window (a prompt of its own length) meets
-    # the first windows of D and E (equal prompts) and sits that round out
-    test_random_scripts_streams_equal_one_stream_at_a_time(monkeypatch, 2024, None, hold=2, n_wins=[2, 1, 1, 1, 1])
+def test_stuck_decoder_windows_with_a_prompt_derived_fallback_token(monkeypatch):
+    """window A hits the decoding limit ending on TEXT, window B hits it too and is skipped as no-speech, so the
+    prompt of window C still ends with A's last token -- the reference then reads the log-probability of an ARBITRARY text
+    token from a window's last row (T.py:498-503).  The B-stream driver keeps that one row whole (StreamRings.last_row):
+    transcribe_batch must give what transcribe() gives, not abort the batch."""
+    import whisper_double as W
+    from whisper_double.decoding import Script, set_row_scripts, set_script
+    W.install()
+    import whisper_timestamped as wt
+    from whisper_timestamped import streams, words
+    cpu_kernel_standin.install(monkeypatch)
+    install_streams_standin(monkeypatch)
+    monkeypatch.setattr(words, "RAW_CONFIDENCE", True)
+    ML, EOT = 50364, 50257
+    model = W.build_model("tiny", seed=0, device="cpu")
+    limit = 24
+    # one open segment each, no closing timestamp, no <|endoftext|>: the token budget ends them ON TEXT (a window with a
+    # timestamp pair would close at the pair and drop its tail instead)
+    a = [ML + 5] + [None] * (limit - 1)                                # the model's most likely tokens: kept
+    b = [ML + 8] + G.text_ids(301, limit - 1)                          # unlikely ids: low avg log-prob -> skipped as no-speech
+    c = G.window_script(ML, EOT, [(10, [None] * 7, 300), (320, [None] * 6, 700)], "eot")
+    g = torch.Generator().manual_seed(77)
+    audios = [(0.05 * torch.randn(int(sec * 16000), generator=g)).float() for sec in (85.0, 70.0, 20.0)]
+    wins = [[a, b, c, c], [a, c, c], [c, c]]
+    opts = dict(language="en", fp16=False, sample_len=limit, no_speech_threshold=1e-12, logprob_threshold=-4.0)
+    singles, recorded = [], []
+    for audio, w_ in zip(audios, wins):
+        sc = set_script(Script(w_))
+        try:
+            singles.append(wt.transcribe(model, audio, **opts))
+        finally:
+            set_script(None)
+        recorded.append(sc.record)
+    assert len(recorded[0]) >= 3                                      # (A, the skipped B, C)
+    scripts = [Script(r) for r in recorded]
+
+    def on_group(idx):
+        for i in idx:
+            scripts[i].begin_window()
+        set_row_scripts([scripts[i] for i in idx])
+    streams.ON_GROUP_DECODE = on_group
+    before = dict(streams.FALLBACK_READS)
+    try:
+        batch = wt.transcribe_batch(model, audios, max_streams=3, **opts)
+    finally:
+        streams.ON_GROUP_DECODE = None
+        set_row_scripts(None)
+    assert streams.FALLBACK_READS["from_the_last_row_kept_whole"] > before["from_the_last_row_kept_whole"]   # the path under test ran
+    n_words = 0
+    for b_, s_ in zip(batch, singles):
+        vb, vs = (json.loads(json.dumps(G.public_view(x), default=float)) for x in (b_, s_))
+        compare(vb, vs, time_tol=0.0, conf_tol=2e-5, logprob_tol=1e-5)
+        n_words += sum(len(x["words"]) for x in vb["segments"])
+    assert n_words > 0
 
 
 def test_degenerate_batches(monkeypatch):
@@ -470,6 +517,17 @@ def check_logits_view(device, write_digest=None):
         asked[2] = 1234 if 1234 not in (int(sampled[2, j]), int(full[2, j].argmax())) else 1235
         with pytest.raises(_lib.WtError, match="not kept"):
             view.gather(asked)
+        # the loop's LAST call is kept whole (StreamRings.keep_last_rows): an arbitrary text token can be asked of it -- the
+        # fallback token a stuck decoder's window takes from the NEXT window's prompt (T.py:498-503)
+        asked[2] = int(sampled[2, j])
+        asked[n_steps - 1] = 4321 if 4321 != int(sampled[n_steps - 1, j]) else 4322
+        with pytest.raises(_lib.WtError, match="not kept"):
+            view.gather(asked)                                           # (not before the row has been declared the last one)
+        rings.keep_last_rows(full[n_steps - 1].to(device), ring_index.long())
+        view.window(host[j], sampled[:, j].tolist(), full_row=n_steps - 1)
+        got = view.gather(asked)
+        want = ref[torch.arange(n_steps), j, torch.tensor(asked)]
+        assert float((got - want).abs().max()) <= 2e-5, (got, want)
     assert int(host[1, 2, 3:4].view(np.int32)[0]) == 700
     return rings, full, sampled, host
 

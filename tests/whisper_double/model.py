@@ -229,7 +229,68 @@ _DIMS = {  # name: (n_mels, audio_state, audio_head, audio_layer, text_state, te
 }
 
 
-def build_model(name: str = "tiny", seed: int = 0, device="cpu", text_layers=None, audio_layers=None) -> Whisper:
+PEAK_STRIDE = 6          # audio frames (of 20 ms) per decoder position of the "peaked" variant: 0.12 s per token
+
+
+def position_codes(t, channels, max_timescale=10000):
+    """sinusoids() at arbitrary (fractional) positions `t`: (len(t), channels)."""
+    log_inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-log_inc * torch.arange(channels // 2))
+    ang = torch.as_tensor(t, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+
+
+def sharpen_cross_attention(model: "Whisper", stride: int = PEAK_STRIDE, gain: float = 1.25, damp: float = 0.05):
+    """Turn a random-init model into one whose cross-attention looks like a TRAINED model's on the alignment heads: the
+    QK logits of decoder position p have a ridge at audio frame p * stride (monotone in p, a few frames wide, ~12 logits
+    above the side lobes) instead of the nearly flat rows random weights give.  Construction (weights only -- the
+    architecture and every code path of the reference and of the product are untouched):
+      * both residual streams are kept close to their position codes: the encoder's second convolution and every block's
+        output projections are damped, so ln_post(x)[f] ~ the sinusoidal code of frame f; the decoder's learned positional
+        embedding is set to 2 x the SAME code family evaluated at frame p * stride;
+      * every head of the model's ``alignment_heads`` mask (and of the reference's table for the model size) gets query /
+        key projections that pick 32 (sin, cos) channel pairs of that code: q . k = sum_k cos(w_k (p * stride - f)).
+    Scripted transcripts whose timestamps follow the same p * stride rule (many_helper.peaked_window) then have their
+    ridge inside each segment's frame window, like speech."""
+    dims = model.dims
+    D = dims.n_text_state
+    assert dims.n_audio_state == D
+    half = D // 2
+    with torch.no_grad():
+        enc, dec = model.encoder, model.decoder
+        enc.conv2.weight.mul_(damp * 0.4)
+        enc.conv2.bias.mul_(damp * 0.4)
+        for blk in list(enc.blocks) + list(dec.blocks):
+            for lin in (blk.attn.out, blk.mlp[2]) + ((blk.cross_attn.out,) if blk.cross_attn is not None else ()):
+                lin.weight.mul_(damp)
+                lin.bias.mul_(damp)
+        for ln in [enc.ln_post] + [blk.cross_attn_ln for blk in dec.blocks]:
+            ln.weight.fill_(1.0)
+            ln.bias.zero_()
+        dev = dec.positional_embedding.device
+        dec.positional_embedding.copy_(2.0 * position_codes(torch.arange(dims.n_text_ctx) * float(stride), D).to(dev))
+        heads = set()
+        if hasattr(model, "alignment_heads"):
+            heads |= {(int(l), int(h)) for l, h in model.alignment_heads.to_dense().nonzero().tolist()}
+        heads |= {(l, h) for l in range(dims.n_text_layer) for h in range(dims.n_text_head)} if dims.n_text_layer <= 4 else set()
+        from_table = {6: [(3, 1), (4, 2), (4, 3), (4, 7), (5, 1), (5, 2), (5, 4), (5, 6)],
+                      12: [(5, 3), (5, 9), (8, 0), (8, 4), (8, 7), (8, 8), (9, 0), (9, 7), (9, 9), (10, 5)]}
+        heads |= set(from_table.get(dims.n_text_layer, []))
+        d_head = D // dims.n_text_head
+        pairs = d_head // 2
+        for l, h in sorted(heads):
+            ca = dec.blocks[l].cross_attn
+            ks = (torch.linspace(0.07, 0.67, pairs) * (half - 1)).round().long() + (h % 3)
+            sel = torch.zeros(d_head, D)
+            sel[torch.arange(pairs), ks] = gain
+            sel[pairs + torch.arange(pairs), half + ks] = gain
+            ca.query.weight[h * d_head:(h + 1) * d_head] = sel.to(ca.query.weight.device)
+            ca.query.bias[h * d_head:(h + 1) * d_head] = 0.0
+            ca.key.weight[h * d_head:(h + 1) * d_head] = sel.to(ca.key.weight.device)
+    return model
+
+
+def build_model(name: str = "tiny", seed: int = 0, device="cpu", text_layers=None, audio_layers=None, attention="flat") -> Whisper:
     """Random-initialised Whisper of the named size (``name`` may end in ``.en``).
 
     The init is chosen so that scripted decoding is well-conditioned: text-token
@@ -237,7 +298,8 @@ def build_model(name: str = "tiny", seed: int = 0, device="cpu", text_layers=Non
     log-prob well above the log-sum-exp of the timestamp tokens), timestamp
     embeddings std 0.04 (the "timestamps dominate" rule of ApplyTimestampRules
     never fires by accident), attention projections std ~1/sqrt(d) * 2 so that
-    cross-attention is not flat.
+    cross-attention is not flat.  ``attention="peaked"``: see sharpen_cross_attention (a monotone ridge on the
+    alignment heads, as a trained model has; "flat" = plain random init, rows nearly flat after the softmax).
     """
     english = name.endswith(".en")
     base = name[:-3] if english else name
@@ -258,4 +320,7 @@ def build_model(name: str = "tiny", seed: int = 0, device="cpu", text_layers=Non
         ts0 = n_vocab - 1501
         emb[ts0:] *= 0.16
         model.decoder.positional_embedding.copy_(torch.randn(448, t_s, generator=g) * 0.1)
+    assert attention in ("flat", "peaked"), attention
+    if attention == "peaked":
+        sharpen_cross_attention(model)
     return model.to(device).eval()

@@ -27,15 +27,23 @@ def merge_gaps(worst, new):
 
 
 NO_GAPS = [0.0, 0.0, 0.0, 0, 0]
-# B streams against ONE stream of the same recording: the alignment kernels are deterministic and batch-independent
-# (tests/test_gpu_parity.py::test_cost_and_jumps_do_not_depend_on_the_batch), but the backend's GEMMs are not bit-identical
-# between a batch of 32 and a batch of 1 (other tile shapes, other accumulation orders: ~1e-6 relative in q and K).  A
-# random-init model's cross-attention is nearly flat, so where the script repeats a token the DTW has near-ties and that
-# noise can move a boundary locally (profiles/r5c_diag_ragged_parity.txt: 4 of 1070 words, one recording, confidences
-# identical to 2e-6; the streams driver run ONE stream at a time equals transcribe() word for word).  Asserted: texts,
-# confidences and mean log-probabilities for every word, times within 0.02 s for at least 99 % of the words; the count and
-# the worst gap are reported.
+# The bar (BASELINE.json north_star): EVERY word's start and end within 0.02 s, confidences within 1e-4 before rounding
+# (mean log-probabilities within 2e-4) -- `gaps_ok`.  It is held on the "peaked" double (whisper_double.model.
+# sharpen_cross_attention: cross-attention with a monotone ridge on the alignment heads, as a trained model has), B streams
+# against ONE stream of the same recording AND against the reference-shaped CPU path.
+#
+# On plain random-init weights ("flat" attention) the same comparison is REPORTED, not gated: the alignment kernels are
+# deterministic and batch-independent (tests/test_gpu_parity.py::test_cost_and_jumps_do_not_depend_on_the_batch), but the
+# backend's GEMMs are not bit-identical between a batch of 32 and a batch of 1 (other tile shapes: ~1e-6 relative in q and
+# K), and where a script repeats a token a flat attention row leaves the DTW near-ties that this noise can flip
+# (profiles/r5c_diag_ragged_parity.txt: 4 of 1070 words, one recording, confidences identical to 2e-6).
+# `gaps_ok_between_batch_sizes` is the round-5 rule for that case (<= 1 % of the words moved); it gates nothing any more.
 MAX_SHARE_OF_WORDS_MOVED_BY_BATCH_ROUNDING = 0.01
+
+
+def gaps_ok(worst):
+    """north_star's bar: every word within 0.02 s, |d confidence| <= 1e-4, |d mean log-prob| <= 2e-4."""
+    return worst[4] == 0 and worst[0] <= 0.02 + 1e-9 and worst[1] <= 1e-4 and worst[2] <= 2e-4
 
 
 PARITY_FAILURES = []      # legs whose parity check did not hold: reported in the line (`parity_failures`), never hidden

@@ -19,8 +19,9 @@ from test_streams_host import install_streams_standin  # noqa: E402
 patch = H._Patch()
 cpu_kernel_standin.install(patch)
 install_streams_standin(patch)
-H.load_base = lambda device: H.load_tiny("cpu")
 torch.cuda.synchronize = lambda *a, **k: None
-args = types.SimpleNamespace(e2e_streams=int(sys.argv[1]) if len(sys.argv) > 1 else 4, no_cpu_baseline=True, e2e_device="cpu", e2e_islands=8)
+args = types.SimpleNamespace(e2e_streams=int(sys.argv[1]) if len(sys.argv) > 1 else 4, no_cpu_baseline="--cpu-path" not in sys.argv,
+                             e2e_device="cpu", e2e_islands=8, e2e_load_model=lambda device, attention="flat": H.load_tiny("cpu", attention),
+                             e2e_cpu_parity_budget=60.0)
 out = run_efficient_leg(args, lambda o: None)
 print(json.dumps(out, indent=1)[:6000])

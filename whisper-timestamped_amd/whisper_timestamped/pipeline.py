@@ -227,7 +227,9 @@ class ChunkBatch:
     parent: object = None
     _n_frames: int = 3000
     _calls: dict = field(default=None, repr=False)
-    # [event, stream it was last recorded on]: the batch's last DTW (reads `cost`) and its last result copy (reads `result`)
+    # [event, stream it was last recorded on]: the batch's last log-mel (writes `mel` in two passes), its last DTW (reads
+    # `cost`) and its last result copy (reads `result`)
+    mel_done: list = field(default_factory=lambda: [torch.cuda.Event(), None], repr=False)
     dtw_done: list = field(default_factory=lambda: [torch.cuda.Event(), None], repr=False)
     copied: list = field(default_factory=lambda: [torch.cuda.Event(), None], repr=False)
 
@@ -378,7 +380,9 @@ class HotPathPipeline:
         write."""
         calls = batch.stage_calls()
         copied = (record.copied,)
-        s.run("logmel", calls["logmel"])
+        # (the front end is two passes over `mel` -- raw log-mel, then the clamp in place: a second submit of the same
+        #  batch on another stream set must not start while the first is between them)
+        s.run("logmel", calls["logmel"], events=(batch.mel_done,), mark=batch.mel_done)
         if batch.fused_small_units:
             s.run("cost", calls["cost"], events=copied)
         else:

@@ -44,6 +44,7 @@ through the batch size of the backend's GEMMs (tests: B = 8 equals eight B = 1 r
 from __future__ import annotations
 
 import logging
+import threading
 
 import numpy as np
 import torch
@@ -61,32 +62,56 @@ N_SAMPLES = 30 * SAMPLE_RATE
 # loop, in row order, right before it starts
 ON_GROUP_DECODE = None
 LAST_RUN = {}
-# Bucket admission (0 / 1 = off): streams share a decoder loop only when their prompts have the same LENGTH.  A stream
-# whose length fewer than HOLD_FOR_BUCKET streams share this round may sit ONE round out -- next round the recordings
-# admitted meanwhile (first windows: equal prompts) or another held stream may join it.  Never two rounds in a row, and
-# never when that would leave the round empty.  Results do not depend on it (a window's result depends on its own prompt).
-HOLD_FOR_BUCKET = 0
+# (Round 5 measured "bucket admission" -- a stream whose prompt length nobody shares sits one round out -- and found no
+#  gain: prompt lengths are spread over ~120 values and holding a stream does not change its length; removed in round 6,
+#  profiles/r5f_bench_driver_command.json `ragged_bucket_admission` keeps the record.)
 PAUSE_GC = True               # pause Python's cyclic garbage collector while a batch decodes (see _run_streams)
+GC_EVERY_ROUNDS = 8           # ... with a young-generation pass every this many rounds (a long batch must not hoard cycles)
 
 
 class paused_gc:
-    """`with paused_gc():` -- the cyclic collector off for the block (when PAUSE_GC and it was on), back on afterwards."""
+    """`with paused_gc():` -- the cyclic collector off for the block (when PAUSE_GC and it was on), back on afterwards and
+    run once.  NB ``gc.disable()`` is PROCESS-global: other threads of a host application are affected for the duration of
+    the batch (set ``streams.PAUSE_GC = False`` there).  Nested / concurrent blocks are counted: the collector comes back
+    when the LAST one exits."""
+    _depth = 0
+    _was_enabled = False
+    _lock = threading.Lock()
 
     def __enter__(self):
         import gc
-        self.was = PAUSE_GC and gc.isenabled()
-        if self.was:
-            gc.disable()
+        self.mine = False
+        if PAUSE_GC:
+            with paused_gc._lock:
+                if paused_gc._depth == 0:
+                    paused_gc._was_enabled = gc.isenabled()
+                    if paused_gc._was_enabled:
+                        gc.disable()
+                paused_gc._depth += 1
+                self.mine = True
+        return self
+
+    def tick(self, rounds):
+        """Called once per round of the driver: a cheap young-generation collection every GC_EVERY_ROUNDS rounds."""
+        if self.mine and GC_EVERY_ROUNDS and rounds % GC_EVERY_ROUNDS == 0:
+            import gc
+            gc.collect(0)
 
     def __exit__(self, *exc):
-        if self.was:
+        if self.mine:
             import gc
-            gc.enable()
+            with paused_gc._lock:
+                paused_gc._depth -= 1
+                last = paused_gc._depth == 0 and paused_gc._was_enabled
+                if last:
+                    gc.enable()
+            if last:
+                gc.collect()
 
 
 # how often a stream's session asked for something other than the sampled token's log-probability (the reference's
 # fallbacks for a stuck decoder): tests / diagnostics
-FALLBACK_READS = {"argmax": 0, "argmax_over_later_timestamps": 0, "logprob_of_another_token": 0}
+FALLBACK_READS = {"argmax": 0, "argmax_over_later_timestamps": 0, "logprob_of_another_token": 0, "from_the_last_row_kept_whole": 0}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -120,6 +145,7 @@ class _LogitsView:
         self.n = 0
         self.host = None                    # (n_calls, 8) fp32: this window's digest records, on the host
         self.sampled = None                 # int64[n_calls]: the token sampled at each call
+        self.full_row = None                # index of the ONE row kept whole (rings.last_row): the loop's final call
 
     def reset(self):
         self.n = 0
@@ -130,8 +156,9 @@ class _LogitsView:
     def __len__(self):
         return self.n
 
-    def window(self, host, sampled):
+    def window(self, host, sampled, full_row=None):
         self.host, self.sampled = host, np.asarray(sampled, dtype=np.int64)
+        self.full_row = full_row
 
     def argmax(self, row, lo=0):
         if row < 0:
@@ -154,9 +181,16 @@ class _LogitsView:
             x = d[4 + r.aux_tokens.index(tok)]
         elif tok >= r.slice_begin:
             x = np.float32(r.slice[self.block, row, tok - r.slice_begin].item())
+        elif self.full_row is not None and row == self.full_row:
+            # a stuck decoder's fallback token taken from the NEXT window's prompt (T.py:498-503) can be any text token;
+            # it is only ever asked of the window's last row when the decoding limit was hit: the loop's final call,
+            # whose rows are kept whole (one per stream)
+            FALLBACK_READS["from_the_last_row_kept_whole"] += 1
+            x = np.float32(r.last_row[self.block, tok].item())
         else:
             raise _lib.WtError(f"streams: the log-probability of token {tok} at step {row} was asked for, which is neither the sampled "
-                               f"token, the most likely one, a special token nor a timestamp: not kept by the B-stream driver")
+                               f"token, the most likely one, a special token nor a timestamp, nor of the loop's last call: not kept "
+                               f"by the B-stream driver")
         return np.float32(np.float32(x - d[1]) - d[2])
 
     def gather(self, tokens):
@@ -191,6 +225,8 @@ class StreamRings:
         self.aux_tokens = [int(tk.eot)] + ([int(tk.no_timestamps)] if tk.no_timestamps is not None else [])
         self.digest = torch.zeros((n_streams, self.capacity, _lib.DIGEST_WORDS), dtype=torch.float32, device=dev)
         self.slice = torch.zeros((n_streams, self.capacity, dims.n_vocab - self.slice_begin), dtype=torch.float32, device=dev)
+        # the filtered logits row of each stream's LAST decoder call of its current loop, whole (V floats per stream)
+        self.last_row = torch.zeros((n_streams, dims.n_vocab), dtype=torch.float32, device=dev)
         self._dt = {torch.float32: _lib.WT_DTYPE_F32, torch.float16: _lib.WT_DTYPE_F16}[dtype]
         self._lib = _lib.load()
         import ctypes as C
@@ -203,11 +239,18 @@ class StreamRings:
         calls = min(dims.n_text_ctx, int(sample_len or dims.n_text_ctx // 2) + 1)
         _, n_slots = layer_head_slots(head_pairs(alignment_heads), len(hooked_blocks), dims.n_text_head)
         item = 2 if dtype == torch.float16 else 4
-        return calls * (max(n_slots, 1) * dims.n_audio_ctx * item + 4 * (_lib.DIGEST_WORDS + dims.n_vocab - int(tokenizer.timestamp_begin)))
+        return calls * (max(n_slots, 1) * dims.n_audio_ctx * item + 4 * (_lib.DIGEST_WORDS + dims.n_vocab - int(tokenizer.timestamp_begin))) \
+            + 4 * dims.n_vocab
 
     def write_digest(self, rows, tokens, ring_index, step):
         """rows (g, V): a decoder call's last-position logits as the sampler left them; tokens (g,): what it sampled."""
+        if rows.dtype != torch.float32:      # a backend whose decoder hands out half-precision logits (the ring copy of round 4 converted)
+            rows = rows.float()
         _lib.logprob_digest_streams(rows, tokens, ring_index, self.digest, self.slice, step, self.aux_tokens, self.slice_begin)
+
+    def keep_last_rows(self, rows, ring_index_long):
+        """The loop's final call: its rows whole, one per stream (what a prompt-derived fallback token is read from)."""
+        self.last_row.index_copy_(0, ring_index_long, rows.float())
 
     def write_qk(self, q_layers, k_layers, ring_index, row):
         """The LAST query row of every selected head, for every stream of the call: q (g, n_q, D), K (g, n_ctx, D) per
@@ -494,9 +537,10 @@ class _Recorder:
             self.lang_outs = outs                          # language detection: (n, 1, V), read by every new stream's session
         self.pending = outs
 
-    def commit(self, sampled):
+    def commit(self, sampled, final=False):
         """The previous call's last-position rows are final (the sampler filtered them in place) and `sampled` (g,) holds
-        the tokens drawn from them: their digests into the ring.  The rows themselves are not kept."""
+        the tokens drawn from them: their digests into the ring.  The rows themselves are not kept -- except those of the
+        loop's LAST call (`final`), one row per stream."""
         if self.pending is None or not self.capture:
             self.pending = None
             return
@@ -505,6 +549,8 @@ class _Recorder:
         if self.verify and step == 0 and self.verify_rows is not None:
             self.verified = (rows.clone(), self.verify_rows)       # compared by the driver with the filters applied
         self.rings.write_digest(rows, sampled, self.ring_index, step)
+        if final:
+            self.rings.keep_last_rows(rows, self.ring_index_long)
         self.pending = None
 
     def check_fused_rows(self, row):
@@ -550,7 +596,6 @@ class _Stream:
         self.prompt_reset_since = 0
         self.done = False
         self.block = index                  # its block of the shared rings (the driver assigns it on admission)
-        self.held = 0                       # rounds in a row this stream sat out waiting for streams with its prompt length
         # the window being decoded
         self.segment_size = 0
         self.task = None
@@ -743,7 +788,10 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                                               opts.get("sample_len"), tk0)
     if dev.type == "cuda":
         # the rings must fit: S streams x (QK rows + digests) next to the model, its KV caches and the whole-file log-mels
-        fit = int(0.5 * torch.cuda.mem_get_info(dev)[0] // max(per_stream, 1))
+        # (free = what the driver reports + what torch's caching allocator holds without using it: a second batch in
+        #  the same process finds the previous rings there)
+        free_bytes = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        fit = int(0.5 * free_bytes // max(per_stream, 1))
         if fit < S:
             logger.warning(f"whisper_timestamped: {S} decoder streams need {S * per_stream / 2**30:.1f} GiB of ring memory; "
                            f"{max(fit, 1)} fit the free device memory -- the other recordings are admitted as streams finish")
@@ -807,7 +855,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
         st.mel = None
         free.append(st.block)
 
-    rounds = groups = held_total = 0
+    rounds = groups = 0
     loop_sizes = []
     verify = efficient.REUSE_DECODER_LOGITS == "auto"
     fused_checked = False
@@ -816,7 +864,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
     # modules, torch's own tables) every few thousand allocations -- a tenth of a 256-stream loop's host time
     # (profiles/r5d_streams_gc.txt).  Paused for the duration of the batch, restored (and run once) at its end.
     try:
-        with torch.no_grad(), paused_gc():
+        with torch.no_grad(), paused_gc() as gc_pause:
             while True:
                 admit()
                 for st in streams:                            # (recordings with nothing to decode: empty audio)
@@ -828,6 +876,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         continue
                     break
                 rounds += 1
+                gc_pause.tick(rounds)
                 # ---- every active stream's prompt for its next window (the backend's own DecodingTask builds it)
                 for st in act:
                     kwargs = {k: opts[k] for k in decode_keys if k in opts}
@@ -839,19 +888,6 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         kwargs.pop("best_of", None)
                     st.task = w.decoding.DecodingTask(model, w.DecodingOptions(**kwargs, temperature=temperature))
                     st.initial_tokens = list(st.task.initial_tokens)
-                # ---- bucket admission: a stream whose prompt length nobody shares this round may sit one round out
-                if HOLD_FOR_BUCKET > 1 and len(act) > 1:
-                    sizes = {}
-                    for st in act:
-                        sizes[len(st.initial_tokens)] = sizes.get(len(st.initial_tokens), 0) + 1
-                    lone = [st for st in act if sizes[len(st.initial_tokens)] < HOLD_FOR_BUCKET and st.held == 0]
-                    if lone and len(lone) < len(act):
-                        for st in lone:
-                            st.held += 1
-                        held_total += len(lone)
-                        act = [st for st in act if st not in lone]
-                for st in act:
-                    st.held = 0
                 # ---- this round's windows, their padding, every stream's prompt call (closes the previous window)
                 mel_batch = torch.stack([st.window_mel() for st in act]).to(dtype)
                 pad = _lib.HostCopy(_lib.find_start_padding(mel_batch.float()))
@@ -879,7 +915,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
                         feats = task._get_audio_features(mel_batch[members])
                         tokens0 = torch.tensor([st.initial_tokens for st in grp], device=dev)
                         tokens, sum_logprobs, no_speech = task._main_loop(feats, tokens0)
-                        rec.commit(tokens[:, -1])             # the last call's rows and what was sampled from them
+                        rec.commit(tokens[:, -1], final=True)  # the last call's rows and what was sampled from them
                     finally:
                         rec.remove()
                     fused_checked = True
@@ -895,7 +931,7 @@ def _run_streams(model, audios, opts, max_streams, **session_kwargs):
         sink.in_flight = []
     LAST_RUN.clear()
     LAST_RUN.update(streams=N, ring_blocks=S, admissions=admissions, rounds=rounds, decoder_loops=groups,
-                    alignment_launch_sets=sink.launch_sets, streams_per_loop=loop_sizes, windows_held_one_round=held_total,
+                    alignment_launch_sets=sink.launch_sets, streams_per_loop=loop_sizes,
                     ring_bytes=int(rings.qk.numel() * rings.qk.element_size() + 4 * (rings.digest.numel() + rings.slice.numel())))
     return out
 
@@ -950,7 +986,7 @@ def _finish_group(grp, task, rec, rings, tokens, sum_logprobs, no_speech, temper
         ses = s.session
         assert rec.calls[0][i] == s.initial_tokens
         n = len(sampled[i])
-        ses.logits.window(host[i, :n], sampled[i])
+        ses.logits.window(host[i, :n], sampled[i], full_row=(n_calls - 1) if n == n_calls else None)
         ses.replay_prompt_logits(no_speech[i])
         mine = sampled[i][:n - 1]                             # the one token fed at calls 1, 2, ...: what call k - 1 sampled
         ts0, k, n = ses.tokenizer.timestamp_begin, 0, len(mine)
