@@ -40,7 +40,19 @@ def available_models():
 
 
 def load_model(name, device=None, download_root=None, in_memory=False):
-    raise RuntimeError("whisper_double has no trained checkpoints (offline image): use whisper_double.build_model(...)")
+    """openai-whisper's ``load_model`` for a checkpoint FILE (``{"dims": {...}, "model_state_dict": {...}}``, SURVEY.md
+    Appendix C); there are no trained checkpoints to fetch by name in this image."""
+    import os
+    import torch
+    if not os.path.isfile(name):
+        raise RuntimeError(f"whisper_double has no trained checkpoints (offline image): {name!r} is not a file; use "
+                           "whisper_double.build_model(...)")
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    checkpoint = torch.load(name, map_location="cpu")
+    net = Whisper(ModelDimensions(**checkpoint["dims"]))
+    net.load_state_dict(checkpoint["model_state_dict"])
+    return net.to(device).eval()
 
 
 def install():
