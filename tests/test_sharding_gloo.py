@@ -338,6 +338,46 @@ def test_recordings_across_two_ranks_streams_within_a_rank(tmp_path):
     assert out.read_text().startswith("ok ")
 
 
+def _collect_worker(rank, world, port, out_path):
+    """sharding.collect_results: every rank's [(index, dictionary)] to rank 0 as flat records in one fixed-size tensor gather
+    ("dicts", "packed") or as pickles ("pickle", rounds 1-5): the same dictionaries in the caller's order, ranks with
+    different numbers of results (one of them with none)."""
+    for p in (ROOT, os.path.join(ROOT, "whisper-timestamped_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from whisper_timestamped.sharding import collect_results
+        cases = json.load(open(os.path.join(ROOT, "tests", "golden", "transcribe_cases.json")))
+        pool = [c["expected"] for c in cases][:11]
+        owner = [0, 1, 1, 0, 1, 1, 0, 1, 1, 1, 0] if world == 2 else [0, 2, 2, 0, 2, 2, 0, 2, 2, 2, 0]     # (3 ranks: rank 1 owns nothing)
+        mine = [(i, pool[i]) for i in range(len(pool)) if owner[i] == rank]
+        for mode in ("dicts", "packed", "pickle"):
+            got = collect_results(dist, mine, len(pool), "cpu", mode)
+            if rank != 0:
+                assert got is None
+                continue
+            if mode == "packed":
+                assert len(got) == len(pool) and got.dict(4) == pool[4]
+                got = got.dicts()
+            assert got == pool, mode
+        if rank == 0:
+            open(out_path, "w").write("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_results_travel_as_flat_records_or_pickles_and_arrive_the_same(tmp_path, world):
+    out = tmp_path / "collect.txt"
+    mp.spawn(_collect_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
 def test_transcribe_many_two_worker_processes_on_the_cpu(monkeypatch):
     """sharding.transcribe_many's process plumbing (spawned workers, largest-first dealing, common start, results back in
     the caller's order) with the kernels replaced by the oracle-backed stand-in: the dictionaries of serial transcribe()

@@ -5,7 +5,9 @@ Alignment units are independent, so the MI355X design is: every rank owns a
 subset of the units (largest-first balancing on T*F, since one DTW's latency
 grows with T+F), runs the kernels with NO data-path collective, and the
 KB-sized per-unit records (jumps[T+1] int32, log-probs[T] fp32) are gathered
-to rank 0, which assembles words/JSON.  Weights are replicated (broadcast once).
+to rank 0, which assembles words/JSON; finished transcribe() dictionaries travel
+as one byte record per recording in one fixed-size tensor gather (records.py),
+decoded on rank 0 when they are read.  Weights are replicated (broadcast once).
 Works with any torch.distributed backend: nccl (= RCCL) on GPUs, gloo in the
 CPU tests.
 """
@@ -166,7 +168,7 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
     reference's `vad=[...]` form, transcribe.py:1944-1947); every island is an independent unit -- exactly the
     reference's transcribe() on that island's crop -- so they are dealt to the ranks largest-first by duration with
     NO data-path collective; every rank transcribes its islands on its own GPU and rank 0 receives the per-island
-    dictionaries (one object gather per job) and merges them (merge_island_results).  Non-zero ranks return None.
+    dictionaries (byte records in one fixed-size tensor gather per job, records.py) and merges them (merge_island_results).  Non-zero ranks return None.
 
     Not the reference's `vad=` mode (that one glues the islands and decodes them as ONE stream, which cannot be split
     without changing what the decoder is conditioned on); per island the results are the reference's.
@@ -203,28 +205,31 @@ def transcribe_islands(model, audio, islands, dist=None, broadcast_weights: bool
             if on_island is not None:
                 on_island(i)
             mine.append((i, transcribe_timestamped(model, crop, **options)))
-    if world > 1:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(mine, gathered, dst=0)
-        if rank != 0:
-            return None
-        mine = [x for part in gathered for x in part]
-    by_index = dict(mine)
-    assert sorted(by_index) == list(range(len(islands)))
-    return merge_island_results([by_index[i] for i in range(len(islands))], islands)
+    per_island = collect_results(dist, mine, len(islands), model.device, "dicts")       # (byte records, one tensor gather)
+    if per_island is None:
+        return None
+    return merge_island_results(per_island, islands)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # Many recordings, many ranks: recordings across the GPUs, decoder streams within a GPU
 # ----------------------------------------------------------------------------------------------------------------------
 def transcribe_recordings(model, audios, dist=None, broadcast_weights: bool = False, streams: int = 32, on_batch=None,
-                          **options):
+                          results: str = "dicts", **options):
     """transcribe_timestamped() of every recording in `audios` on all ranks of `dist` (one process per GPU).  Recordings
     are independent units: dealt to the ranks largest-first by length (`partition_units`), no data-path collective;
     each rank steps ITS recordings through the decoder together, up to `streams` per decoder op (`transcribe_batch`);
-    rank 0 receives the result dictionaries with one object gather per job and returns them in the order of `audios`
-    (the other ranks return None).  Every rank passes the same `audios` list (paths, arrays or tensors; a rank only
-    loads its own).  `on_batch(indices)` is called on each rank with its recordings' indices, in stream order."""
+    rank 0 receives the results and returns them in the order of `audios` (the other ranks return None).  Every rank
+    passes the same `audios` list (paths, arrays or tensors; a rank only loads its own).  `on_batch(indices)` is called on
+    each rank with its recordings' indices, in stream order.
+
+    How the results travel (`results`; measured at 8 ranks x 32 recordings, tools/measure_result_gather.py):
+      "dicts"   one byte record per recording in ONE fixed-size tensor gather (records.gather_packed), every record decoded
+                on rank 0 -- the same list of dictionaries transcribe() would give, one per recording;
+      "packed"  the same gather, and rank 0 returns the records.PackedResults table: a dictionary is built when somebody
+                asks for it (``table.dict(i)``), so rank 0's serial share of the job is the gather alone;
+      "pickle"  rounds 1-5: one ``dist.gather_object`` per job (every object of every rank rebuilt inside the collective)."""
+    assert results in ("dicts", "packed", "pickle"), results
     from .naive import get_audio_tensor
     from .transcribe import transcribe_batch
     rank = 0 if dist is None else dist.get_rank()
@@ -243,15 +248,34 @@ def transcribe_recordings(model, audios, dist=None, broadcast_weights: bool = Fa
     if on_batch is not None:
         on_batch(idx)
     mine = list(zip(idx, transcribe_batch(model, [get_audio_tensor(audios[i]) for i in idx], max_streams=streams, **options)))
-    if world > 1:
+    return collect_results(dist, mine, len(audios), model.device, results)
+
+
+def collect_results(dist, mine, n_total, device, results="dicts"):
+    """[(index, transcribe() dictionary)] of every rank -> rank 0 (see transcribe_recordings); None on the other ranks."""
+    rank = 0 if dist is None else dist.get_rank()
+    world = 1 if dist is None else dist.get_world_size()
+    if world > 1 and results == "pickle":
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(mine, gathered, dst=0)
         if rank != 0:
             return None
         mine = [x for part in gathered for x in part]
+    elif world > 1:
+        from . import records
+        table = records.gather_packed(dist, mine, device)
+        if rank != 0:
+            return None
+        assert sorted(table.indices) == list(range(n_total))
+        return table if results == "packed" else table.dicts()
+    elif results == "packed":
+        from . import records
+        table = records.table_of([records.pack_many(mine)])
+        assert sorted(table.indices) == list(range(n_total))
+        return table
     by_index = dict(mine)
-    assert sorted(by_index) == list(range(len(audios)))
-    return [by_index[i] for i in range(len(audios))]
+    assert sorted(by_index) == list(range(n_total))
+    return [by_index[i] for i in range(n_total)]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
