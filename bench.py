@@ -98,10 +98,6 @@ def parse_args(argv=None):
     ap.add_argument("--leg", default="fp32", choices=["fp32", "fp16", "efficient", "recordings"], help=argparse.SUPPRESS)
     ap.add_argument("--e2e-streams", type=int, default=32,
                     help="recordings per decoder op of the default-strategy leg (transcribe_batch; 32 = BASELINE configs[1])")
-    ap.add_argument("--e2e-worker-processes", type=int, default=0,
-                    help="default-strategy leg: worker processes of the ragged long-form sub-leg (0 / 1 = skip it, the default: "
-                         "measured once, profiles/r5h_*: 4 processes x 8 streams = 1.33x one process x 32 streams -- the "
-                         "processes' small kernels serialise on the one device)")
     ap.add_argument("--out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--secondary", action="store_true", help=argparse.SUPPRESS)     # a kernel leg of another BASELINE config
     ap.add_argument("--dry-run", action="store_true",

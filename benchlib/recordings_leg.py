@@ -86,7 +86,9 @@ def role_recordings(args):
         dist.barrier()
         sync()
         t0 = time.perf_counter()
-        res = transcribe_recordings(model, audios, dist=dist, broadcast_weights=dry, streams=n_streams, on_batch=on_batch, **opts)
+        # results="packed": one byte record per recording in one fixed-size tensor gather; rank 0 decodes what it reads
+        res = transcribe_recordings(model, audios, dist=dist, broadcast_weights=dry, streams=n_streams, on_batch=on_batch,
+                                    results="packed", **opts)
         sync()
         mine = time.perf_counter() - t0
         dist.barrier()
@@ -97,7 +99,11 @@ def role_recordings(args):
     every = [None] * world
     dist.all_gather_object(every, round(mine, 4))
     if rank == 0:
-        assert len(res) == len(audios) and all(len(r["segments"]) > 0 for r in res)
+        assert len(res) == len(audios) and all(res.nbytes(i) > 0 for i in range(len(audios)))
+        t_dec = time.perf_counter()
+        every_result = res.dicts()                         # (what a caller that wants every dictionary at once would pay on rank 0)
+        t_dec = time.perf_counter() - t_dec
+        assert all(len(r["segments"]) > 0 for r in every_result)
         worst = NO_GAPS
         picks = sorted({0, len(audios) // 2, len(audios) - 1})
         for k in picks:                                    # recordings other ranks decoded, against one stream here
@@ -106,14 +112,15 @@ def role_recordings(args):
                 alone = wt.transcribe(model, audios[k], **opts)
             finally:
                 set_script(None)
-            worst = merge_gaps(worst, word_gaps(words_of(res[k]), words_of(alone), f"recording {k} (another rank) vs one stream"))
+            worst = merge_gaps(worst, word_gaps(words_of(res.dict(k)), words_of(alone), f"recording {k} (another rank) vs one stream"))
         parity_flag(gaps_ok_between_batch_sizes(worst), "transcribe_recordings", gaps_report(worst))
         emit({"parity_failures": list(PARITY_FAILURES), "what": "sharding.transcribe_recordings: ragged recordings (U[5, 30] s, own transcripts) dealt to the ranks, "
                       f"{n_streams} decoder streams per rank, weights broadcast from rank 0 (every other rank started from "
-                      "perturbed weights), result dictionaries gathered to rank 0",
+                      "perturbed weights), one byte record per recording gathered to rank 0 in one fixed-size tensor gather",
               "ranks": world, "recordings": len(audios), "recordings_per_rank": per_rank, "audio_seconds": round(sum(secs), 1),
               "seconds": round(el, 3), "audio_s_per_s": round(sum(secs) / el, 1), "scaling": "weak",
-              "per_rank_seconds": every, "backend": "gloo (dry run)" if dry else "rccl",
+              "per_rank_seconds": every, "results": "packed (records.py): decoded on demand",
+              "decoding_every_result_on_rank_0_seconds": round(t_dec, 4), "backend": "gloo (dry run)" if dry else "rccl",
               "parity_vs_1_stream_on_rank_0": gaps_report(worst, {"recordings_compared": picks})})
     dist.barrier()
     dist.destroy_process_group()

@@ -28,6 +28,7 @@ def results_pool():
 def worker(rank, world, per_rank, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)                    # (N ranks share this host's cores; a GPU box gives every rank its share)
     pool = results_pool()
     # (distinct objects: pickle would send a repeated dictionary once and a back-reference afterwards)
     mine = [(rank * per_rank + k, json.loads(json.dumps(pool[(rank * per_rank + k) % len(pool)]))) for k in range(per_rank)]
@@ -53,8 +54,8 @@ def worker(rank, world, per_rank, port, out):
                    "packed_bytes_per_recording_mean": int(records.pack_many(mine).nbytes / len(mine)),
                    "rank0_seconds_per_job": {k: round(v, 5) for k, v in report.items()},
                    "rank0_microseconds_per_recording": {k: round(1e6 * v / (world * per_rank), 1) for k, v in report.items()},
-                   "what": {"pickle": "dist.gather_object (rounds 1-5)", "dicts": "flat records, one tensor gather, every dictionary "
-                            "rebuilt on rank 0", "packed": "flat records, one tensor gather, dictionaries built on demand"},
+                   "what": {"pickle": "dist.gather_object (rounds 1-5)", "dicts": "one byte record per recording, one tensor gather, every "
+                            "record decoded on rank 0", "packed": "the same gather, records decoded on demand (none here)"},
                    "backend": "gloo (host memory, this container)", "cpus": os.cpu_count()}, open(out, "w"))
     dist.destroy_process_group()
 

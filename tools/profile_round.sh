@@ -36,10 +36,6 @@ find "$out" -name "*.csv" -size +2M -delete
 
 tail -1 "$out/bench.json"; head -14 "$out/kernel_stats.txt"; head -30 "$out/e2e_kernel_stats.txt" 2>/dev/null
 # secondary workloads (one line each) and the transcribe()-level traces: plain decoding vs the timestamped data planes
-for w2 in kfull256 kreal largev3_fp16; do
-  timeout 300 python $ROOT/bench.py --workload $w2 --steps 10 --warmup 3 --e2e off --no-cpu-baseline > "$out/bench_$w2.json" 2> "$out/bench_$w2.err" || true
-done
-timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --e2e off --no-cpu-baseline --graph > "$out/bench_graph.json" 2>> "$out/bench.err" || true
 WT_BENCH_FORCE_DIST=1 timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 --e2e off --no-cpu-baseline > "$out/bench_force_dist_rccl_1rank.json" 2>> "$out/bench.err" || true
 timeout 300 python $ROOT/tools/bench_transcribe.py base > "$out/timestamp_overhead.json" 2> "$out/timestamp_overhead.err" || true
 timeout 300 python $ROOT/tools/bench_transcribe.py small > "$out/timestamp_overhead_small.json" 2>> "$out/timestamp_overhead.err" || true
