@@ -139,6 +139,8 @@ def run_child(role, extra, timeout_s, env=None):
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--role", role, "--out", path] + list(extra)
     err = None
     # its own session: a leg that has to be stopped takes its own children (worker processes) with it
+    env = dict(os.environ if env is None else env)
+    env.setdefault("WT_BENCH_DUMP_STACKS_AFTER", str(max(5, timeout_s - 15)))
     proc = subprocess.Popen(cmd, stdout=sys.stderr, env=env, start_new_session=True)      # children never write to stdout
     try:
         rc = proc.wait(timeout=timeout_s)
@@ -329,6 +331,11 @@ def main():
     # children: stdout belongs to the parent's single JSON line -- everything libraries print goes to stderr
     sys.stdout.flush()
     os.dup2(2, 1)
+    # a leg that is still running shortly before its parent gives up on it says where (every thread's Python stack)
+    dump_after = float(os.environ.get("WT_BENCH_DUMP_STACKS_AFTER", "0") or 0)
+    if dump_after > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(dump_after, exit=False, file=sys.stderr)
     if args.role == "kernel":
         from benchlib.kernel_leg import role_kernel
         role_kernel(args)

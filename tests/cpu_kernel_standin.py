@@ -15,7 +15,7 @@ from oracle import align_ref as O
 def install(monkeypatch):
     from whisper_timestamped import _lib, alignment, batched, capture, efficient
     monkeypatch.setattr(efficient, "GPU_FRONT_END", False)      # the backend's own torch.stft on the CPU
-    monkeypatch.setattr(batched, "SCHEDULE", "serial")          # no HIP streams on the CPU: everything in program order
+    monkeypatch.setattr(batched, "SCHEDULE", "serial")          # (the default) no HIP streams on the CPU: program order
     monkeypatch.setattr(efficient, "FUSED_ATTENTION", False)    # qk observed on the unfused path, as in the reference
 
     monkeypatch.setattr(_lib, "require_gpu", lambda device, what="": None)

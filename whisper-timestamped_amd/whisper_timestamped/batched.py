@@ -22,11 +22,12 @@ exists in the other branch (:1147-1152) -- so B of them can share every launch:
 ``bench.py`` 32 synthetic chunks (BASELINE.json configs[1] at the transcribe() level).  Sub-batches are pipelined:
 the GPU work of sub-batch k+1 is queued before the host assembles the words of sub-batch k.
 
-Streams (``SCHEDULE``; whisper_timestamped/pipeline.py): sub-batch k runs on StageSet k % 2 -- the model's GEMMs, the QK-row
-pass, the cost stage and the log-probability gather on the set's low-priority HIP stream, the log-mel front end and the
-DTW on its high-priority one, dependencies as events -- so the latency-bound DTW and the VALU-bound STFT of one sub-batch
-run beside the other kernels instead of in front of them.  ``SCHEDULE = "serial"`` keeps everything on the caller's
-current stream (what rounds 1-5 did); results are bit-identical either way (tests/test_gpu_transcribe.py).
+Streams (``SCHEDULE``; whisper_timestamped/pipeline.py): the model's GEMMs, the QK-row pass, the cost stage and the
+log-probability gather stay on the caller's current stream, in order; the log-mel front end and the DTW of sub-batch k go
+to high-priority HIP stream k % 2 of the aligner's own, dependencies as events (pipeline.StageSet) -- so the latency-bound
+DTW of sub-batch k and the VALU-bound STFT of sub-batch k + 1 run beside the other kernels instead of in front of them.
+``SCHEDULE = "serial"`` (the default: see below) keeps everything on the caller's current stream; results are
+bit-identical either way (tests/test_gpu_transcribe.py).
 """
 from __future__ import annotations
 
@@ -46,7 +47,12 @@ logger = logging.getLogger("whisper_timestamped")
 
 N_SAMPLES = N_FRAMES * HOP_LENGTH     # 480000: one 30 s window
 MAX_WINDOWS_PER_LAUNCH = 32           # BASELINE.json configs[1]; bounds the (B, T_max, V) logits block (base: 0.6 GB)
-SCHEDULE = "auto"                     # pipeline.choose_schedule: "auto" | "hilo" | "serial" (serial = the caller's current stream)
+# "serial" (default) = every stage on the caller's current stream; "hilo" = the front end and the DTW on high-priority
+# streams of the aligner's own (pipeline.StageSet).  Measured on the fp32 whisper-base leg, 32 windows per launch set
+# (profiles/r6d_batched_hang_variants.txt): hilo 23.59-23.68 k audio-s/s, serial 23.77 k -- the model's GEMMs are 99 % of the
+# GPU time there, the alignment stages have nothing to hide behind -- so the default stays serial; hilo is kept, tested
+# bit-identical, for models whose forward pass is cheap next to the alignment (tiny models, half precision).
+SCHEDULE = "serial"
 
 
 @dataclass
@@ -117,7 +123,7 @@ class BatchedAligner:
         self.n_mels = model.dims.n_mels if hasattr(model.dims, "n_mels") else 80
         self.workspace = default_workspace(self.dev)
         self.timeline = None            # set to [] to collect per-sub-batch GPU stage times (ms) -- bench.py does
-        self.schedule = pipeline.choose_schedule(SCHEDULE, MAX_WINDOWS_PER_LAUNCH)
+        self.schedule = pipeline.choose_schedule(SCHEDULE, MAX_WINDOWS_PER_LAUNCH)     # ("auto" = the pipeline's rule: hilo)
         self._stage_sets, self._launches = None, 0
         # (Rounds 2-3 carried an opt-in replay of the forward pass as one captured HIP graph per shape.  Since round 3 the
         #  eager half-precision pass is GPU-bound -- 96 % busy in its own process -- so a replay could gain 4 % at most, and
@@ -156,22 +162,28 @@ class BatchedAligner:
             st.marks.append((name, ev))
 
     def _next_stage_set(self):
-        """StageSet of the next sub-batch (two, alternating), or None under the serial schedule."""
+        """StageSet of the next sub-batch, or None under the serial schedule: the caller's CURRENT stream as the set's
+        low-priority lane (everything torch launches -- the model's GEMMs, the QK-row pass, the cost stage, the gather --
+        stays on one stream, in order, sub-batch after sub-batch) and one of two high-priority streams of the aligner's own,
+        alternating, for the log-mel front end and the DTW.  Two sub-batches' GEMMs never run side by side: with a
+        low-priority stream per sub-batch the fp32 model's forward passes of two sub-batches overlapped and the device
+        hung in the backend's GEMM kernels, nondeterministically (profiles/r6d_batched_hang_variants.txt)."""
         if self.schedule != "hilo":
             return None
-        if self._stage_sets is None:
-            with _lib.device_ctx(self.dev):
-                self._stage_sets = [pipeline.StageSet(self.dev, "hilo") for _ in range(2)]
-        self._launches += 1
-        return self._stage_sets[self._launches % 2]
+        with _lib.device_ctx(self.dev):
+            if self._stage_sets is None:
+                self._stage_sets = [pipeline.priority_stream(self.dev, "high") for _ in range(2)]
+            self._launches += 1
+            return pipeline.StageSet(self.dev, "hilo", streams=(self._stage_sets[self._launches % 2],
+                                                                 torch.cuda.current_stream(self.dev)))
 
     def close(self):
         """Free the library's scratch arenas of the aligner's own streams (after the last collect())."""
         if self._stage_sets is not None:
             with _lib.device_ctx(self.dev):
-                for s in self._stage_sets:
-                    s.synchronize()
-                    s.release()
+                for hi in self._stage_sets:
+                    hi.synchronize()
+                    _lib.release_stream(hi)
             self._stage_sets = None
 
     # ------------------------------------------------------------------ the model's forward pass
@@ -197,13 +209,7 @@ class BatchedAligner:
 
     # ------------------------------------------------------------------ device: one sub-batch, nothing waits
     def launch(self, jobs) -> _Stage:
-        ss = self._next_stage_set()
-        if ss is None:
-            return self._launch(jobs, None)
-        with _lib.device_ctx(self.dev):
-            ss.lo.wait_stream(torch.cuda.current_stream(self.dev))      # the jobs' PCM was produced on the caller's stream
-            with torch.cuda.stream(ss.lo):                              # every buffer of the sub-batch belongs to this stream
-                return self._launch(jobs, ss)
+        return self._launch(jobs, self._next_stage_set())
 
     def _launch(self, jobs, ss) -> _Stage:
         tk, dev = self.tk, self.dev
@@ -225,29 +231,40 @@ class BatchedAligner:
             assert n <= N_SAMPLES, f"window {b}: {n} samples > 30 s (the batched path takes whisper's 30 s seek groups)"
             n_valid[b] = n
         with _lib.device_ctx(dev), torch.no_grad():
-            pcm = torch.zeros((B, N_SAMPLES), dtype=torch.float32, device=dev)
-            for b, job in enumerate(st.jobs):
-                pcm[b, :n_valid[b]].copy_(job.pcm.reshape(-1), non_blocking=True)
-            small = self._to_device(np.concatenate([tok_mat.reshape(-1), n_valid]), st.keep)
-            tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
+            def stage_pcm():
+                pcm_ = torch.zeros((B, N_SAMPLES), dtype=torch.float32, device=dev)
+                for b_, job_ in enumerate(st.jobs):
+                    pcm_[b_, :n_valid[b_]].copy_(job_.pcm.reshape(-1), non_blocking=True)
+                return pcm_
             # log-mel of every crop, zero padded to 3000 frames (:1211-1215), and where the padding starts (:1795-1805)
             if ss is None:
+                pcm = stage_pcm()
+                small = self._to_device(np.concatenate([tok_mat.reshape(-1), n_valid]), st.keep)
+                tok_dev, nv_dev = small[:B * T_max].view(B, T_max), small[B * T_max:]
                 self._mark(st, "logmel<")
                 mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True)
                 pad_copy = _lib.HostCopy(pad)
                 self._mark(st, "logmel>")
+                del pcm
             else:
-                # on the set's high-priority stream, behind the uploads; the model waits for it by event
-                ss.run("upload", lambda st_: None)
-                ss.wait_for(ss.hi, ("upload",))
-                self._mark(st, "logmel<", ss.hi)
-                mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True,
-                                                  launch=lambda fn: ss.run("logmel", fn))
+                # The whole front end -- staging the crops, the STFT, the padding index and its copy to the host -- on the
+                # set's high-priority stream: queued NOW, beside whatever the previous sub-batch still has on the caller's
+                # stream; the model waits for it by event.  Buffers allocated under that stream and read on the caller's
+                # (mel) are handed over with record_stream.
+                cur = torch.cuda.current_stream(dev)
+                ss.hi.wait_stream(cur)                                  # the jobs' PCM was produced on the caller's stream
                 with torch.cuda.stream(ss.hi):
+                    pcm = stage_pcm()
+                    nv_dev = self._to_device(n_valid, st.keep)
+                    self._mark(st, "logmel<", ss.hi)
+                    mel, pad = wt_audio.log_mel_batch(pcm, nv_dev, n_mels=self.n_mels, n_frames=N_FRAMES, with_padding=True,
+                                                      launch=lambda fn: ss.run("logmel", fn))
                     pad_copy = _lib.HostCopy(pad)
-                self._mark(st, "logmel>", ss.hi)
-                ss.wait_for(ss.lo, ("logmel",))
-            del pcm
+                    self._mark(st, "logmel>", ss.hi)
+                    del pcm
+                mel.record_stream(cur)
+                ss.wait_for(cur, ("logmel",))
+                tok_dev = self._to_device(tok_mat.reshape(-1), st.keep).view(B, T_max)
             self._mark(st, "model<")
             # encoder + teacher-forced decoder on the whole batch (:1236-1238); no logit filters on this path (:1245)
             x = mel if self.mel_dtype is None else mel.to(self.mel_dtype)
