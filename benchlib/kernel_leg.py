@@ -138,7 +138,7 @@ def role_kernel(args):
     def timed_region(pipelined=False):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks; seconds."""
         if single is not None:
-            single.sets[0].timeline.clear()
+            single.sets[0].start_timeline(True)           # (the previous region's stage times have been read: events recycled)
         if dist is not None:
             dist.barrier()
         sync()

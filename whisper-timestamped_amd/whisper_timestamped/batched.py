@@ -326,7 +326,7 @@ class BatchedAligner:
             if ss is not None and ss.timeline:
                 # the DTW ran on the set's other stream: its own event pair (start = its cost stage done)
                 st.marks.extend(m for stage, ev0, ev1 in ss.timeline if stage == "dtw" for m in (("dtw<", ev0), ("dtw>", ev1)))
-                ss.start_timeline(False)
+                ss.timeline = None                  # (the events live on in st.marks: not recycled)
             self._mark(st, "logprob<")
             if n_gather and batch.units:
                 gt = self._to_device(np.concatenate([np.asarray(gather_rows, dtype=np.int32),

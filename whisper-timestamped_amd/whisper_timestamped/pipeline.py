@@ -108,6 +108,7 @@ class StageSet:
         self._own = {}
         self._since_join = []
         self.timeline = [] if timeline else None     # [(stage, start_event, end_event)] when asked for
+        self._timing_pool = []
         self._last_mark = None
 
     @classmethod
@@ -117,9 +118,20 @@ class StageSet:
         return cls(device, "serial", streams=(cur, cur), timeline=timeline)
 
     def start_timeline(self, on: bool = True):
-        """Collect (stage, start_event, end_event) for every stage run from now on (``on=False``: stop, drop what was kept)."""
+        """Collect (stage, start_event, end_event) for every stage run from now on (``on=False``: stop, drop what was kept).
+        The timing events of the entries dropped here are recycled (their times must have been read by now)."""
+        if self.timeline:
+            seen = set()
+            for _, ev0, ev1 in self.timeline:
+                for ev in (ev0, ev1):
+                    if id(ev) not in seen:
+                        seen.add(id(ev))
+                        self._timing_pool.append(ev)
         self.timeline = [] if on else None
         self._last_mark = None
+
+    def _timing_event(self):
+        return self._timing_pool.pop() if self._timing_pool else torch.cuda.Event(enable_timing=True)
 
     def stream_of(self, stage):
         return self.hi if LANE.get(stage, "lo") == "hi" else self.lo
@@ -141,7 +153,7 @@ class StageSet:
             if self._last_mark is not None and self._last_mark[1] is st:
                 start = self._last_mark[0]
             else:
-                start = torch.cuda.Event(enable_timing=True)
+                start = self._timing_event()
                 start.record(st)
         fn(st.cuda_stream)
         if mark is not None:
@@ -155,7 +167,7 @@ class StageSet:
         self.events[stage] = (ev, st)
         self._since_join.append(stage)
         if self.timeline is not None:
-            end = torch.cuda.Event(enable_timing=True)
+            end = self._timing_event()
             end.record(st)
             self.timeline.append((stage, start, end))
             self._last_mark = (end, st)
