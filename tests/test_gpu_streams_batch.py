@@ -8,6 +8,8 @@ this repository's own one-stream path: a batch of eight equals eight single call
 import copy
 import json
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -102,14 +104,21 @@ def test_half_precision_model_streams_stay_close():
 @pytest.mark.gpu
 def test_logprob_digest_streams_kernel_against_the_full_rows():
     """wt_logprob_digest_streams (the real kernel through the C ABI) under the same checks as the host test's stand-in,
-    and: record [0] is BIT-identical to wt_logprob_gather_batch on the same rows and tokens."""
+    and: record [0] is BIT-identical to wt_logprob_gather_batch on the same rows and tokens -- rows at the same
+    address alignment, as check_logits_view lays them out (the last query row of a (g, 3, V) block): both kernels start
+    their vector stream on the row's first 128-byte boundary, so the alignment decides which thread sums which logits."""
     from test_streams_host import check_logits_view
     from whisper_timestamped import _lib
     rings, full, sampled, host = check_logits_view("cuda:0")
     n_steps, g, V = full.shape
     for step in range(n_steps):
-        lp = _lib.logprob_gather(full[step].cuda(), sampled[step].to(torch.int32).cuda()).cpu().numpy()
+        outs = torch.zeros((g, 3, V))
+        outs[:, -1] = full[step]
+        lp = _lib.logprob_gather(outs.cuda()[:, -1], sampled[step].to(torch.int32).cuda()).cpu().numpy()
         assert (lp == host[:, step, 0]).all(), (step, lp, host[:, step, 0])
+        # any other alignment: another summation order, the same value within the path's bar
+        lp2 = _lib.logprob_gather(full[step].cuda(), sampled[step].to(torch.int32).cuda()).cpu().numpy()
+        assert np.abs(lp2 - host[:, step, 0]).max() <= 2e-5
 
 
 @pytest.mark.parametrize("attention", ["peaked", "flat"])

@@ -77,16 +77,6 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {  // fixed summation tre
     return (a + b) + (c + d);
 }
 
-// exp(t) for t <= 0 on v_exp_f32 with a compensated log2(e) product (<= ~1.5 ulp; ocml's expf costs twice the VALU).
-// t may be a large negative sentinel (-1e30) but not -inf.
-__device__ __forceinline__ float exp_nonpos(float t) {
-    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299e-8f, LN2 = 0.693147182f;
-    const float yh = t * L2E_HI;
-    const float yl = fmaf(t, L2E_LO, fmaf(t, L2E_HI, -yh));
-    const float e = __builtin_amdgcn_exp2f(yh);
-    return fmaf(e, yl * LN2, e);
-}
-
 // s_waitcnt vmcnt(0) only (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8])
 __device__ __forceinline__ void wait_vmcnt0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
