@@ -220,6 +220,7 @@ WT_API int wt_find_start_padding_batch(const float *mel, int n_chunks, int n_mel
  * logits, gather of the chosen token T.py:735) and T.py:1245,1292 (naive).
  * For each of n_rows rows of V fp32 logits (row r at logits + r*row_stride):
  *     out[r] = log_softmax(row with suppressed entries at -inf)[token[r]]
+ *   (a NaN logit makes out[r] NaN, as F.log_softmax does; the reference asserts finiteness at T.py:736)
  *   suppress      : optional device uint8[n_rows_or_1][V] (1 = -inf), or NULL
  *   suppress_rows : 0 = none, 1 = one shared mask row, n_rows = per-row masks */
 WT_API int wt_logprob_gather_batch(const void *logits, int logits_dtype, int64_t row_stride, int n_rows, int V,
@@ -236,7 +237,7 @@ WT_API int wt_logprob_gather_rows(const void *logits, int logits_dtype, int64_t 
  * (T.py:875-876) until the window closes; here, when a decoder call's rows are final (the sampler has filtered them in
  * place, the sampled tokens are known), ONE launch takes from each row everything the hook state machine can still
  * ask of it, and the row itself is not kept:
- *   digest[blk][ring_row][0]    log_softmax(row)[token]      (T.py:735; bit-identical to wt_logprob_gather_batch)
+ *   digest[blk][ring_row][0]    log_softmax(row)[token]      (T.py:735; bit-identical to wt_logprob_gather_batch on a row at the same address modulo 128 bytes)
  *   digest[blk][ring_row][1..2] max(row), log(sum(exp(row - max))):  log_softmax(row)[t] = (row[t] - [1]) - [2]
  *   digest[blk][ring_row][3]    argmax(row) as int32 bits, first index of the maximum   (T.py:508,729,879)
  *   digest[blk][ring_row][4..7] row[aux_tokens[k]] (raw logits; -inf for k >= n_aux): <|endoftext|>, <|notimestamps|> ...
