@@ -324,6 +324,9 @@ def cap_threads_per_rank():
 
 
 def main():
+    # multi-process GPU work on this pool's hosts (dmabuf IPC only): without it RCCL's communicator set-up fails with
+    # hipIpcGetMemHandle: invalid argument.  Before the first HIP call; the children and self-launched ranks inherit it.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args()
     cap_threads_per_rank()
     if args.role == "orchestrate":
