@@ -66,6 +66,7 @@ class AlignmentUnit:
     detect_disfluencies: bool
     tokenizer: object
     tag: object = None          # caller's handle
+    mel: object = None          # the window's log-mel, kept for the debug figure only (plot_word_alignment)
 
     @property
     def T(self):
@@ -245,8 +246,13 @@ class AlignmentBatch:
     copy brings everything to the host."""
 
     def __init__(self, medfilt_width=9, qk_scale=1.0, keep_cost=False, want_path=False, workspace=None, extra_words=0,
-                 subwords_can_be_empty=True, stage_set=None):
+                 subwords_can_be_empty=True, stage_set=None, plot=False):
         self.units: list[AlignmentUnit] = []
+        # plot_word_alignment (True: show, "<prefix>": save): one figure per unit once its words exist -- collect() then
+        # reads the units' cost matrices and warping paths back (plotting.py); nothing changes for plot=False
+        self.plot = plot
+        if plot:
+            keep_cost = want_path = True
         self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
         # transcribe.py:1571-1580: symmetric1, or the pattern without the previous-token/same-frame move
         self.step_pattern = _lib.WT_STEP_SYMMETRIC1 if subwords_can_be_empty else _lib.WT_STEP_NO_EMPTY_SUBWORDS
@@ -427,9 +433,22 @@ class AlignmentBatch:
             js = starts_host[j0:j0 + u.T + 1].astype(np.int64) if starts_host is not None else None
             out[order[k]] = finish_unit(u, jm, js)
             self._slot_of[order[k]] = k
+        if self.plot:
+            self._draw(out, jumps_host)
+            self.release()
         if not self.keep_cost:                       # the cost matrices live in the slot: hand it back unless asked to keep
             self.release()
         return out
+
+    def _draw(self, out, jumps_host):
+        """plot_word_alignment: one figure per unit, in the caller's order (transcribe.py:1586-1646, 1685-1700, 1756-1781)."""
+        from . import plotting
+        for i, unit in enumerate(self.units):
+            d = self.descs[self._slot_of[i]]
+            j0 = int(d["jumps_offset"])
+            path_tokens, path_frames = self.unit_path(i)
+            plotting.alignment_figure(unit, self.unit_cost(i).cpu().numpy(), path_tokens.cpu().numpy(), path_frames.cpu().numpy(),
+                                      jumps_host[j0:j0 + unit.T + 1], out[i], self.plot)
 
     def run(self):
         return self.launch().collect()
@@ -498,8 +517,6 @@ def perform_word_alignment(tokens, attention_weights, tokenizer, use_space=True,
                            plot=False, debug=False):
     """Drop-in for the reference function (same arguments, same list of
     dict(text, start, end, tokens, tokens_indices)); the numerics run on the GPU."""
-    if plot:
-        raise NotImplementedError("plot_word_alignment: debug plotting is out of scope (SURVEY.md section 2, row 17)")
     unit = prepare_unit(tokens, attention_weights, tokenizer, use_space=use_space, mfcc=mfcc,
                         refine_whisper_precision_nframes=refine_whisper_precision_nframes,
                         remove_punctuation_from_words=remove_punctuation_from_words,
@@ -510,6 +527,8 @@ def perform_word_alignment(tokens, attention_weights, tokenizer, use_space=True,
         if debug:
             logger.debug(f"Got empty segment in {tokenizer.decode_with_timestamps(list(tokens))}")
         return []
-    batch = AlignmentBatch(medfilt_width=medfilt_width, qk_scale=qk_scale, subwords_can_be_empty=subwords_can_be_empty)
+    batch = AlignmentBatch(medfilt_width=medfilt_width, qk_scale=qk_scale, subwords_can_be_empty=subwords_can_be_empty, plot=plot)
+    if plot:
+        unit.mel = mfcc
     batch.add(unit)
     return batch.run()[0]

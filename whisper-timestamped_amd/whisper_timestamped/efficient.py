@@ -77,7 +77,7 @@ class EfficientSession:
     def __init__(self, model, whisper_options, *, remove_punctuation_from_words, compute_word_confidence,
                  include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
                  word_alignment_most_top_layers, detect_disfluencies, trust_whisper_timestamps,
-                 use_timestamps_for_alignment=True, ring_dtype=None, ring=None, logits=None, sink=None):
+                 use_timestamps_for_alignment=True, ring_dtype=None, ring=None, logits=None, sink=None, plot=False):
         """``ring`` / ``logits`` / ``sink``: the B-stream form (streams.py).  One session per decoder stream, fed with the
         RECORDED events of a batched decoder call instead of live hooks: its attention rows and logits rows live in its
         block of rings shared by all streams (views handed in here), and the alignment units of all streams of a window
@@ -92,6 +92,7 @@ class EfficientSession:
         self.detect_disfluencies = detect_disfluencies
         self.trust = trust_whisper_timestamps
         self.use_timestamps_for_alignment = use_timestamps_for_alignment
+        self.plot = plot                 # plot_word_alignment: a figure per aligned segment (plotting.py)
 
         self.temperature = whisper_options["temperature"]
         self.no_speech_threshold = whisper_options["no_speech_threshold"]
@@ -512,6 +513,8 @@ class EfficientSession:
                 ws = [dict(text=text, start=None, end=None, tokens=pieces, tokens_indices=ids)
                       for text, pieces, ids in planned_words(unit, with_text=True)]
                 if ws:
+                    if self.plot:
+                        unit.mel = self.mfcc
                     self.queued.append((unit, ws, self._padding_handle(self.mfcc)))
         else:
             unit = prepare_unit(tokens, None, tk, use_space=backend.should_use_space(self.language),
@@ -522,7 +525,9 @@ class EfficientSession:
             if unit is None:
                 ws = []
             else:
-                batch = AlignmentBatch(workspace=self.workspace)
+                batch = AlignmentBatch(workspace=self.workspace, plot=self.plot)
+                if self.plot:
+                    unit.mel = self.mfcc
                 batch.add(unit)
                 ws = batch.run()[0]
         added = len(ws) > 0
@@ -542,7 +547,7 @@ class EfficientSession:
             return
         previous, self.in_flight = self.in_flight, []
         if self.queued:
-            batch = AlignmentBatch(workspace=self.workspace)
+            batch = AlignmentBatch(workspace=self.workspace, plot=self.plot)
             for unit, _, handle in self.queued:
                 if handle is not None:
                     sp = int(handle[1].wait()[0])
@@ -866,8 +871,6 @@ def transcribe_efficient(model, audio, *, remove_punctuation_from_words, compute
                          include_punctuation_in_confidence, refine_whisper_precision_nframes, alignment_heads,
                          plot_word_alignment, word_alignment_most_top_layers, detect_disfluencies,
                          trust_whisper_timestamps, use_timestamps_for_alignment=True, **whisper_options):
-    if plot_word_alignment:
-        raise NotImplementedError("plot_word_alignment is out of scope (debug plotting)")
     verbose = whisper_options["verbose"]
     whisper_options["verbose"] = None if verbose is True else verbose     # words are printed by the caller
     if verbose and whisper_options["language"] is None and getattr(model, "is_multilingual", False):
@@ -879,7 +882,7 @@ def transcribe_efficient(model, audio, *, remove_punctuation_from_words, compute
                                alignment_heads=alignment_heads,
                                word_alignment_most_top_layers=word_alignment_most_top_layers,
                                detect_disfluencies=detect_disfluencies, trust_whisper_timestamps=trust_whisper_timestamps,
-                               use_timestamps_for_alignment=use_timestamps_for_alignment)
+                               use_timestamps_for_alignment=use_timestamps_for_alignment, plot=plot_word_alignment)
     out = session.run(audio)
     if verbose and session.detected_language:
         print(f"Detected language: {backend.whisper().tokenizer.LANGUAGES[session.language].title()}")

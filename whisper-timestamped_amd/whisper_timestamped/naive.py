@@ -65,8 +65,6 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
                      include_punctuation_in_confidence, refine_whisper_precision_nframes, use_backend_timestamps,
                      alignment_heads, plot_word_alignment, word_alignment_most_top_layers, detect_disfluencies,
                      trust_whisper_timestamps, min_word_duration, **whisper_options):
-    if plot_word_alignment:
-        raise NotImplementedError("plot_word_alignment is out of scope (debug plotting)")
     w = backend.whisper()
     verbose = whisper_options["verbose"]
     whisper_options["verbose"] = None if verbose is True else verbose
@@ -259,7 +257,7 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
             start_sample = min(round(start * SAMPLE_RATE), audio.shape[-1])
             end_sample = min(round(end * SAMPLE_RATE), audio.shape[-1])
 
-            if not trust_whisper_timestamps and BATCH_WINDOWS:
+            if not trust_whisper_timestamps and BATCH_WINDOWS and not plot_word_alignment:    # (figures: one window at a time)
                 # whisper's 30 s seek groups do not depend on each other (:1197-1202): queue the window, all of them go
                 # through mel / encoder / decoder / alignment / confidence gather together (batched.py)
                 if audio_dev is None:
@@ -320,7 +318,9 @@ def transcribe_naive(model, audio, *, remove_punctuation_from_words, compute_wor
             if unit is None:
                 ws = []
             else:
-                batch = AlignmentBatch()
+                batch = AlignmentBatch(plot=plot_word_alignment)
+                if plot_word_alignment:
+                    unit.mel = mfcc
                 batch.add(unit)
                 ws = batch.run()[0]
 

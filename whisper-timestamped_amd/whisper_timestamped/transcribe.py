@@ -131,7 +131,8 @@ def transcribe_timestamped(
     Accepted by the signature but NOT supported here (the call raises ``NotImplementedError``):
     ``vad=True / "silero" / "auditok"`` (the detectors are third-party models that need network access -- pass the
     speech islands as ``vad=[(start, end), ...]``, which runs the reference's glue / back-conversion),
-    ``plot_word_alignment`` (debug plots), and a HuggingFace ``transformers`` model object as ``model``.
+    and a HuggingFace ``transformers`` model object as ``model``.  ``plot_word_alignment=True`` shows, a string saves
+    (``<prefix>.alignment<NNN>.jpg``, ``<prefix>.VAD.jpg``) the reference's debug figures (plotting.py; needs matplotlib).
     Module switches that trade exact reference arithmetic for speed are listed in INTEGRATION.md ("Switches")."""
     plan = _plan(model, locals())
     model, audio = plan["model"], audio
@@ -139,6 +140,9 @@ def transcribe_timestamped(
         torch.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
     vad, naive_approach = plan["vad"], plan["naive_approach"]
+    if plot_word_alignment:
+        from . import plotting
+        plotting.reset()                       # (transcribe.py:300-301: figures are numbered per call)
     if vad is not None:
         audio = get_audio_tensor(audio)
         audio, vad_segments, convert_timestamps = remove_non_speech(audio, method=vad, sample_rate=SAMPLE_RATE,

@@ -96,8 +96,6 @@ def do_convert_timestamps(segments, t, t2=None):
 def remove_non_speech(audio, use_sample=False, min_speech_duration=0.1, min_silence_duration=1, dilatation=0.5,
                       sample_rate=SAMPLE_RATE, method=None, avoid_empty_speech=False, plot=False):
     """-> (speech-only audio, islands [(start, end)], convert(t, t2=None))."""
-    if plot:
-        raise NotImplementedError("plotting is out of scope")
     segments = get_vad_segments(audio, sample_rate=sample_rate, output_sample=True,
                                 min_speech_duration=min_speech_duration, min_silence_duration=min_silence_duration,
                                 dilatation=dilatation, method=method)
@@ -108,6 +106,9 @@ def remove_non_speech(audio, use_sample=False, min_speech_duration=0.1, min_sile
         else:
             return torch.Tensor([]), [], lambda t, t2=None: t if t2 is None else [t, t2]
     audio_speech = torch.cat([audio[..., s:e] for s, e in segments], dim=-1)
+    if plot:                                  # transcribe.py:2139-2150
+        from . import plotting
+        plotting.vad_figure(audio, segments, sample_rate, plot)
     if not use_sample:
         segments = [(float(s) / sample_rate, float(e) / sample_rate) for s, e in segments]
     return audio_speech, segments, lambda t, t2=None: do_convert_timestamps(segments, t, t2)
