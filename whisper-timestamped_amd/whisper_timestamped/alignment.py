@@ -251,6 +251,7 @@ class AlignmentBatch:
         # plot_word_alignment (True: show, "<prefix>": save): one figure per unit once its words exist -- collect() then
         # reads the units' cost matrices and warping paths back (plotting.py); nothing changes for plot=False
         self.plot = plot
+        self._release_after_figures = bool(plot) and not keep_cost     # (a caller that asked for the matrices keeps them)
         if plot:
             keep_cost = want_path = True
         self.medfilt_width, self.qk_scale = medfilt_width, qk_scale
@@ -435,7 +436,8 @@ class AlignmentBatch:
             self._slot_of[order[k]] = k
         if self.plot:
             self._draw(out, jumps_host)
-            self.release()
+            if self._release_after_figures:
+                self.release()
         if not self.keep_cost:                       # the cost matrices live in the slot: hand it back unless asked to keep
             self.release()
         return out
