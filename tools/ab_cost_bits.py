@@ -41,7 +41,8 @@ def batch(seed, shapes, n_heads, sort):
     L.cost_batch(qk, descs, dd, heads, cost)
     torch.cuda.synchronize()
     c = cost.cpu().numpy()
-    assert np.isfinite(c[:n_cost]).all()
+    for d in descs:                                    # (the layout may leave gaps between units: those stay NaN)
+        assert np.isfinite(c[int(d['cost_offset']):int(d['cost_offset']) + int(d['T']) * int(d['F'])]).all()
     return hashlib.sha256(c.tobytes()).hexdigest()
 
 
